@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the LINE-2D match() hot path on MI355X.
+
+A step = one Detector::match (line2Dup.cpp:1078-1150) of one frame that is
+already resident in HBM: gradient quantisation -> pyramid -> spread/response/
+linearize -> similarity over this rank's template shard -> 16x16 refinement ->
+match records, all-gathered over RCCL when N > 1 and copied to pinned host
+memory.  Metric: templates * Mpixels / s (BASELINE.json), whole job.
+
+Workload (BASELINE.json configs[1], "case1 on 1x MI355X"): the reference's
+case1 test image centred on a 1024 x 1024 BGR canvas, 360 case1 rotation
+templates (131 / 71 features) per GPU, pyramid {4, 8}, threshold 90.  With N
+GPUs the template set is N x 360 (weak scaling), sharded by contiguous ranges.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+ROWS = COLS = 1024
+N_TEMPLATES = 360
+THRESHOLD = 90.0
+T_LEVELS = (4, 8)
+PREFETCH = 4096  # match records copied to the host with the count, per step
+
+
+def load_workload(world: int):
+    from shape_based_matching_amd import synth
+    from shape_based_matching_amd.templates import TemplateSet
+
+    golden = os.path.join(ROOT, "tests", "golden")
+    base = TemplateSet.load_npz(os.path.join(golden, "case1_templates.npz")).subset(range(N_TEMPLATES))
+    shards = []
+    for r in range(world):
+        s = base.subset(range(N_TEMPLATES))
+        s.class_ids = [f"test{r}"]
+        shards.append(s)
+    ts = TemplateSet.concat(shards)
+    img = np.load(os.path.join(golden, "case1_test_bgr.npz"))["bgr"]
+    frame = synth.embed(img, ROWS, COLS, (ROWS - img.shape[0]) // 2, (COLS - img.shape[1]) // 2)
+    return ts, frame
+
+
+def cpu_baseline(ts, frame, budget_s: float = 12.0):
+    """The CPU oracle (a port of the reference algorithm, OpenMP over templates like
+    line2Dup.cpp:1166-1170) timed on this host on the same frame and templates."""
+    from oracle import oracle as O
+
+    ncpu = os.cpu_count() or 1
+
+    def run(threads, reps):
+        t0 = time.perf_counter()
+        n = 0
+        for _ in range(reps):
+            pyr = O.Pyramid.build(frame, list(T_LEVELS), 30.0)
+            recs = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, THRESHOLD, n_threads=threads)
+            n = len(recs)
+            pyr.free()
+        return (time.perf_counter() - t0) / reps, n
+
+    t1, n1 = run(1, 2)
+    tn, _ = run(ncpu, 2) if ncpu > 1 else (t1, n1)
+    threads = 1 if t1 <= tn else ncpu
+    per = min(t1, tn)
+    reps = max(3, int(budget_s / per))
+    per, n = run(threads, reps)
+    value = ts.n_templates * (frame.shape[0] * frame.shape[1] / 1e6) / per
+    return {
+        "value": value,
+        "unit": "templates*Mpixels/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{reps} full match() calls of the bench frame with {ts.n_templates} templates "
+                  f"({per * 1e3:.1f} ms each, {n} raw matches); host has {ncpu} logical cores",
+        "ms_per_match": per * 1e3,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from shape_based_matching_amd import capi, sharding
+    from shape_based_matching_amd.templates import MATCH_DTYPE
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    ts, frame = load_workload(world)
+    first, count = sharding.partition(sharding.coarse_work(ts, ROWS, COLS, T_LEVELS), world)[rank]
+
+    ctx = capi.Context(T=T_LEVELS, weak_threshold=30.0, device_id=local_rank)
+    ctx.upload_templates(ts)
+    ctx.select_range(first, count)
+
+    d_img = torch.from_numpy(frame).to(dev)
+    cap = PREFETCH
+    d_out = torch.zeros(cap * MATCH_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    gath_out = torch.zeros(world * cap * MATCH_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    gath_cnt = torch.zeros(world * 2, dtype=torch.int32, device=dev)
+    h_out = torch.zeros(world * cap * MATCH_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
+    h_cnt = torch.zeros(world * 2, dtype=torch.int32).pin_memory()
+    stream = torch.cuda.current_stream()
+
+    def step():
+        ctx.match_device(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, d_out.data_ptr(), cap,
+                         d_cnt.data_ptr(), stream=stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gath_cnt, d_cnt)
+            dist.all_gather_into_tensor(gath_out, d_out)
+            h_cnt.copy_(gath_cnt, non_blocking=True)
+            h_out.copy_(gath_out, non_blocking=True)
+        else:
+            h_cnt.copy_(d_cnt, non_blocking=True)
+            h_out.copy_(d_out, non_blocking=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # the match list of the last step, as the host sees it
+    counts = h_cnt.numpy().reshape(world, 2)
+    if (counts[:, 1] != 0).any() or (counts[:, 0] > cap).any():
+        raise SystemExit(f"match list overflow: {counts.tolist()}")
+    recs = h_out.numpy().view(MATCH_DTYPE).reshape(world, cap)
+    matches = np.concatenate([recs[r, : counts[r, 0]] for r in range(world)])
+    n_matches = len(capi.canonicalize(matches))
+
+    # per-kernel durations: a second pass of the same steps with HIP events around every launch
+    # (on the launch stream), kept out of the timed region above
+    ctx.set_profiling(True)
+    per_kernel = {}
+    prof_steps = min(args.steps, 50)
+    for _ in range(prof_steps):
+        ctx.match_device(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, d_out.data_ptr(), cap,
+                         d_cnt.data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        for name, ms in ctx.timings():
+            per_kernel.setdefault(name, []).append(ms)
+    ctx.set_profiling(False)
+    n_cand, refine_bytes = ctx.stats()
+    coarse_bytes = ctx.coarse_bytes()
+
+    if rank == 0:
+        # algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md), by kernel
+        npx = [(ROWS >> l) * (COLS >> l) for l in range(len(T_LEVELS))]
+        alg = {
+            "k_quantize": [npx[0] * (3 + 1), npx[1] * (3 + 1)],
+            "k_build_lm": [npx[0] * 9, npx[1] * 9],
+            "k_pyrdown": [npx[0] * 3 + npx[1] * 3],
+            "k_similarity_coarse": [coarse_bytes],
+            "k_similarity_local": [refine_bytes],
+        }
+        kern = {}
+        for name, v in per_kernel.items():
+            launches = len(v) // prof_steps
+            a = np.asarray(v).reshape(prof_steps, launches)
+            kern[name] = {"ms_per_step": float(a.sum(axis=1).mean()), "launches": launches,
+                          "avg_launch_us": float(a.mean() * 1e3)}
+        dom = max((k for k in kern if k in alg), key=lambda k: kern[k]["ms_per_step"])
+        dom_bytes = float(sum(alg[dom])) / kern[dom]["launches"]
+        dom_s = kern[dom]["avg_launch_us"] * 1e-6
+        achieved = dom_bytes / dom_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom)
+            except Exception:
+                traffic = None
+        total_templates = ts.n_templates
+        value = total_templates * (ROWS * COLS / 1e6) * args.steps / elapsed
+        out = {
+            "metric": "templates*Mpixels/sec (whole Detector::match, frame resident in HBM)",
+            "value": value,
+            "unit": "templates*Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "reference case1 test image (test/case1/test.png) centred on a black 1024x1024 BGR canvas; "
+                    "case1 rotation templates 0..359 (test/case1/test_templ.yaml)",
+            "config": {
+                "workload": "case1 on MI355X: 1024x1024x3 frame x 360 templates per GPU (131/71 features), "
+                            "pyramid T={4,8}, threshold 90, match list gathered to the host every step",
+                "templates_total": total_templates,
+                "templates_per_gpu": count,
+                "frame": [ROWS, COLS, 3],
+                "parallelism": f"template-shard x{world}" + (" + RCCL all-gather of match lists" if world > 1 else ""),
+                "matches_distinct": n_matches,
+                "coarse_candidates_rank0": n_cand,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": dom_bytes,
+                "avg_launch_us": kern[dom]["avg_launch_us"],
+            },
+            "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base_ts = ts.subset(range(first, first + count))
+            out["cpu_baseline"] = cpu_baseline(base_ts, frame, args.cpu_budget)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+/*
+ * sbm.h — C ABI of libsbm_hip.so, the MI355X (gfx950) LINE-2D matching engine.
+ *
+ * This is the drop-in boundary for the match() hot path of
+ * ddcr/shape_based_matching.  The reference has no FFI layer: its boundary is
+ * the C++ class line2Dup::Detector (line2Dup.h:257-333).  include/line2Dup.h in
+ * this repository re-declares that class and implements it on top of the
+ * functions below, so a reference caller (test.cpp, test_jabil.cpp) re-links
+ * against this library unchanged; other hosts bind the C ABI directly
+ * (INTEGRATION.md shows both).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success or a negative sbm_status, with a message available from
+ * sbm_last_error() (thread-local).  One context drives one GPU; a context is
+ * not thread-safe, different contexts may be used concurrently.  "host"
+ * pointers are ordinary process memory, "device" pointers are HBM addresses on
+ * the context's GPU (e.g. torch tensors' data_ptr()), `stream` is a
+ * hipStream_t passed as void* (NULL = the context's own stream).
+ *
+ * Each entry point cites the reference function (file:line) it replaces.
+ */
+#ifndef SBM_H
+#define SBM_H
+
+#include <stdint.h>
+#include "sbm_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBM_ABI_VERSION 1
+
+typedef enum sbm_status {
+    SBM_OK = 0,
+    SBM_ERR_INVALID = -1,   /* bad argument (CV_Assert / CV_Error in the reference) */
+    SBM_ERR_HIP = -2,       /* HIP runtime failure or no usable GPU */
+    SBM_ERR_CAPACITY = -3,  /* candidate / match buffer too small */
+    SBM_ERR_STATE = -4      /* call sequence error (no templates, no pyramid, ...) */
+} sbm_status;
+
+typedef struct sbm_ctx sbm_ctx;
+
+/* Detector constructor arguments that matter to match()
+ * (line2Dup.cpp:1056-1076: pyramid_levels, T_at_level, ColorGradient::weak_threshold). */
+typedef struct sbm_config {
+    int32_t n_levels;
+    int32_t T[SBM_MAX_LEVELS];
+    float weak_threshold;
+    int32_t device_id;
+    int64_t max_candidates; /* capacity of the coarse-candidate and match lists; 0 = 1<<20 */
+} sbm_config;
+
+const char* sbm_last_error(void);
+int sbm_abi_version(void);
+
+int sbm_create(const sbm_config* cfg, sbm_ctx** out);
+void sbm_destroy(sbm_ctx* ctx);
+
+/* ---- templates ----------------------------------------------------------
+ * Replaces the in-memory TemplatesMap the reference walks in matchClass
+ * (line2Dup.h:319-321, line2Dup.cpp:1160-1172).  levels is [n_templates][n_levels]
+ * (level 0 first), features is the flat array the levels index into;
+ * class_idx / template_id label the emitted matches (either may be NULL:
+ * class 0 / id = position).  Templates with >= 8192 features at any level are
+ * rejected with SBM_ERR_INVALID (CV_Error, line2Dup.cpp:1195, :1260). */
+int sbm_upload_templates(sbm_ctx* ctx, int32_t n_templates, const sbm_template_level* levels,
+                         const sbm_feature* features, int64_t n_features,
+                         const int32_t* class_idx, const int32_t* template_id);
+
+/* Restrict matching to templates whose class_idx is listed (Detector::match's
+ * class_ids argument, line2Dup.cpp:1124-1140).  n == 0 selects every class.  A
+ * second form selects an explicit template index range [first, first+count):
+ * the template shard of one GPU (reference analogue: the OpenMP loop bounds,
+ * line2Dup.cpp:1169-1170). */
+int sbm_select_classes(sbm_ctx* ctx, const int32_t* class_idx, int32_t n);
+int sbm_select_range(sbm_ctx* ctx, int32_t first, int32_t count);
+
+/* ---- whole hot path -----------------------------------------------------
+ * Detector::match (line2Dup.cpp:1078-1150) without the final std::sort /
+ * std::unique: emits the pre-dedup multiset of matches in unspecified order;
+ * sbm_canonicalize() applies the epilogue.  img is 8-bit, 1 or 3 interleaved
+ * channels (BGR order as cv::imread gives), row stride in bytes; mask (rows x
+ * cols, non-zero = keep) may be NULL.  rows/cols must satisfy the reference's
+ * preconditions at every level (rows_l % T_l == 0, cols_l % T_l == 0,
+ * (rows_l * cols_l) % 16 == 0; line2Dup.cpp:639, :751-752) else SBM_ERR_INVALID. */
+int sbm_match(sbm_ctx* ctx, const uint8_t* img_host, int32_t rows, int32_t cols, int32_t stride,
+              int32_t channels, const uint8_t* mask_host, float threshold, sbm_match_rec* out_host,
+              int64_t cap, int64_t* n_out);
+
+/* Same path with the frame already resident in HBM.  Asynchronous: enqueues
+ * every kernel on `stream` and returns.  Results go to caller-provided device
+ * buffers (d_out: cap records, d_count: one int32 — the number of matches,
+ * which may exceed cap, in which case only cap records were stored) so the host
+ * side can all-gather them over RCCL without another copy. */
+int sbm_match_device(sbm_ctx* ctx, const void* d_img, int32_t rows, int32_t cols, int32_t stride,
+                     int32_t channels, const void* d_mask, float threshold, void* d_out,
+                     int64_t cap, void* d_count, void* stream);
+
+/* Detector::match epilogue (line2Dup.cpp:1142-1145) in canonical form: sort by
+ * (similarity desc, template_id asc, class_idx asc, y asc, x asc), drop exact
+ * duplicates.  Host-side, in place; returns the new count. */
+int64_t sbm_canonicalize(sbm_match_rec* recs, int64_t n);
+
+/* ---- pyramid state ------------------------------------------------------
+ * sbm_build_pyramid: the first half of match() (line2Dup.cpp:1084-1120):
+ * quantizedOrientations -> [pyrDown -> quantizedOrientations]* -> per level
+ * quantize(mask) -> spread -> computeResponseMaps -> linearize, leaving the
+ * flat linear memories of every level resident in HBM. */
+int sbm_build_pyramid(sbm_ctx* ctx, const uint8_t* img_host, int32_t rows, int32_t cols,
+                      int32_t stride, int32_t channels, const uint8_t* mask_host);
+/* Install a caller-made one-hot orientation map as level `level` of the
+ * pyramid and build its linear memories (spread -> computeResponseMaps ->
+ * linearize; line2Dup.cpp:1110-1116).  Levels must be set from 0 upwards. */
+int sbm_set_quantized(sbm_ctx* ctx, int32_t level, const uint8_t* quantized_host, int32_t rows,
+                      int32_t cols);
+/* Read back what a level holds: its one-hot map (rows*cols) and its flat
+ * linear memories ([8][lm_stride] bytes; lm_stride >= T*T*W*H, zero tail). */
+int sbm_get_quantized(sbm_ctx* ctx, int32_t level, uint8_t* out_host);
+int sbm_get_linear_memories(sbm_ctx* ctx, int32_t level, uint8_t* out_host, int64_t cap_bytes,
+                            int64_t* lm_stride);
+int sbm_level_dims(sbm_ctx* ctx, int32_t level, int32_t* rows, int32_t* cols);
+
+/* Second half of match(): Detector::matchClass over the selected templates
+ * (line2Dup.cpp:1160-1297) against the resident pyramid. */
+int sbm_match_templates(sbm_ctx* ctx, float threshold, sbm_match_rec* out_host, int64_t cap,
+                        int64_t* n_out);
+
+/* ---- single reference functions (stage entry points; host arrays) --------
+ * Each runs the HIP kernel that replaces one reference function and copies the
+ * result back, so it can be tested (and adopted) on its own. */
+
+/* quantizedOrientations + hysteresisGradient (line2Dup.cpp:313-404, 218-311).
+ * magnitude / angle_ori (float, rows*cols) may be NULL; angle is the one-hot map. */
+int sbm_quantized_orientations(sbm_ctx* ctx, const uint8_t* img_host, int32_t rows, int32_t cols,
+                               int32_t stride, int32_t channels, float weak_threshold,
+                               float* magnitude, uint8_t* angle, float* angle_ori);
+/* cv::pyrDown as called by ColorGradientPyramid::pyrDown (line2Dup.cpp:431-433). */
+int sbm_pyrdown(sbm_ctx* ctx, const uint8_t* img_host, int32_t rows, int32_t cols, int32_t stride,
+                int32_t channels, uint8_t* out_host);
+/* spread (line2Dup.cpp:616-630). */
+int sbm_spread(sbm_ctx* ctx, const uint8_t* src_host, int32_t rows, int32_t cols, int32_t T,
+               uint8_t* dst_host);
+/* computeResponseMaps (line2Dup.cpp:637-747): maps_host is [8][rows*cols]. */
+int sbm_compute_response_maps(sbm_ctx* ctx, const uint8_t* spread_host, int32_t rows, int32_t cols,
+                              uint8_t* maps_host);
+/* linearize (line2Dup.cpp:749-777): lm_host is [T*T][(rows/T)*(cols/T)]. */
+int sbm_linearize(sbm_ctx* ctx, const uint8_t* map_host, int32_t rows, int32_t cols, int32_t T,
+                  uint8_t* lm_host);
+/* similarity / similarity_64 (line2Dup.cpp:807-858, 924-984) of uploaded
+ * template `template_index` at the coarsest level of the resident pyramid:
+ * dst_host is the H x W uint16 score map. */
+int sbm_similarity(sbm_ctx* ctx, int32_t template_index, uint16_t* dst_host);
+/* similarityLocal / similarityLocal_64 (line2Dup.cpp:860-922, 986-1048) at
+ * pyramid level `level` around centre (cx, cy): dst_host is 16 x 16 uint16. */
+int sbm_similarity_local(sbm_ctx* ctx, int32_t level, int32_t template_index, int32_t cx,
+                         int32_t cy, uint16_t* dst_host);
+
+/* ---- measurement ---------------------------------------------------------
+ * Per-kernel HIP-event timings of the last sbm_match/sbm_build_pyramid/
+ * sbm_match_templates call when profiling was enabled (adds synchronisation;
+ * never enabled in the throughput path). names/ms arrays hold up to cap entries. */
+int sbm_set_profiling(sbm_ctx* ctx, int32_t enabled);
+int sbm_get_timings(sbm_ctx* ctx, const char** names, float* ms, int32_t cap, int32_t* n);
+/* Algorithmic bytes of the coarse pass for the selected templates on the
+ * resident pyramid: sum over in-bounds coarsest-level features of
+ * max(template_positions, 0)  (SURVEY.md 8d). */
+int sbm_coarse_bytes(sbm_ctx* ctx, int64_t* bytes);
+
+/* Counters of the last template-matching call: coarse candidates found
+ * (line2Dup.cpp:1208-1214) and the algorithmic bytes of the refinement passes,
+ * sum over refined candidates of nf_level * 256.  Synchronises. */
+int sbm_get_stats(sbm_ctx* ctx, int64_t* n_candidates, int64_t* refine_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBM_H */

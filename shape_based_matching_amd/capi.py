@@ -1,0 +1,291 @@
+"""ctypes binding of libsbm_hip.so (the C ABI declared in include/sbm.h).
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is
+visible, every call raises.  The library is built in-tree by
+``__graft_entry__.build()`` / ``make -C shape_based_matching_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .templates import FEATURE_DTYPE, LEVEL_DTYPE, MATCH_DTYPE, TemplateSet
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsbm_hip.so")
+SBM_MAX_LEVELS = 8
+
+# every symbol include/sbm.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "sbm_last_error", "sbm_abi_version", "sbm_create", "sbm_destroy", "sbm_upload_templates",
+    "sbm_select_classes", "sbm_select_range", "sbm_match", "sbm_match_device", "sbm_canonicalize",
+    "sbm_build_pyramid", "sbm_set_quantized", "sbm_get_quantized", "sbm_get_linear_memories",
+    "sbm_level_dims", "sbm_match_templates", "sbm_quantized_orientations", "sbm_pyrdown", "sbm_spread",
+    "sbm_compute_response_maps", "sbm_linearize", "sbm_similarity", "sbm_similarity_local",
+    "sbm_set_profiling", "sbm_get_timings", "sbm_coarse_bytes", "sbm_get_stats",
+]
+
+
+class SbmConfig(C.Structure):
+    _fields_ = [
+        ("n_levels", C.c_int32),
+        ("T", C.c_int32 * SBM_MAX_LEVELS),
+        ("weak_threshold", C.c_float),
+        ("device_id", C.c_int32),
+        ("max_candidates", C.c_int64),
+    ]
+
+
+class SbmError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libsbm_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libsbm_hip.so; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is not built (run __graft_entry__.build()); "
+            "shape_based_matching_amd has no CPU fallback"
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    L.sbm_last_error.restype = C.c_char_p
+    L.sbm_abi_version.restype = i32
+    L.sbm_create.argtypes = [C.POINTER(SbmConfig), C.POINTER(vp)]
+    L.sbm_destroy.argtypes = [vp]
+    L.sbm_destroy.restype = None
+    L.sbm_upload_templates.argtypes = [vp, i32, vp, vp, i64, vp, vp]
+    L.sbm_select_classes.argtypes = [vp, vp, i32]
+    L.sbm_select_range.argtypes = [vp, i32, i32]
+    L.sbm_match.argtypes = [vp, vp, i32, i32, i32, i32, vp, f32, vp, i64, C.POINTER(i64)]
+    L.sbm_match_device.argtypes = [vp, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp]
+    L.sbm_canonicalize.argtypes = [vp, i64]
+    L.sbm_canonicalize.restype = i64
+    L.sbm_build_pyramid.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    L.sbm_set_quantized.argtypes = [vp, i32, vp, i32, i32]
+    L.sbm_get_quantized.argtypes = [vp, i32, vp]
+    L.sbm_get_linear_memories.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
+    L.sbm_level_dims.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.sbm_match_templates.argtypes = [vp, f32, vp, i64, C.POINTER(i64)]
+    L.sbm_quantized_orientations.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]
+    L.sbm_pyrdown.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    L.sbm_spread.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.sbm_compute_response_maps.argtypes = [vp, vp, i32, i32, vp]
+    L.sbm_linearize.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.sbm_similarity.argtypes = [vp, i32, vp]
+    L.sbm_similarity_local.argtypes = [vp, i32, i32, i32, i32, vp]
+    L.sbm_set_profiling.argtypes = [vp, i32]
+    L.sbm_get_timings.argtypes = [vp, vp, vp, i32, C.POINTER(i32)]
+    L.sbm_coarse_bytes.argtypes = [vp, C.POINTER(i64)]
+    L.sbm_get_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    for name in ABI_SYMBOLS:
+        f = getattr(L, name)
+        if name not in ("sbm_last_error", "sbm_destroy", "sbm_canonicalize"):
+            f.restype = i32
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise SbmError(rc, lib().sbm_last_error().decode("utf-8", "replace"))
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _img(img: np.ndarray) -> Tuple[np.ndarray, int, int, int]:
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if img.ndim == 2:
+        return img, img.shape[0], img.shape[1], 1
+    if img.ndim == 3 and img.shape[2] in (1, 3):
+        return img, img.shape[0], img.shape[1], img.shape[2]
+    raise ValueError("image must be HxW or HxWx{1,3} uint8")
+
+
+def canonicalize(recs: np.ndarray) -> np.ndarray:
+    recs = np.ascontiguousarray(recs, MATCH_DTYPE).copy()
+    n = lib().sbm_canonicalize(_p(recs), len(recs))
+    return recs[:n]
+
+
+class Context:
+    """One GPU context (``sbm_ctx``)."""
+
+    def __init__(self, T: Sequence[int] = (4, 8), weak_threshold: float = 30.0, device_id: int = 0,
+                 max_candidates: int = 0):
+        cfg = SbmConfig()
+        cfg.n_levels = len(T)
+        for i, t in enumerate(T):
+            cfg.T[i] = int(t)
+        cfg.weak_threshold = float(weak_threshold)
+        cfg.device_id = int(device_id)
+        cfg.max_candidates = int(max_candidates)
+        self.T = [int(t) for t in T]
+        self.n_levels = len(T)
+        self._h = C.c_void_p()
+        _check(lib().sbm_create(C.byref(cfg), C.byref(self._h)))
+        self._cap = max_candidates if max_candidates > 0 else 1 << 20
+        self.n_templates = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().sbm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- templates ------------------------------------------------------------
+    def upload_templates(self, ts: TemplateSet):
+        if ts.n_levels != self.n_levels:
+            raise ValueError(f"template pyramids have {ts.n_levels} levels, detector has {self.n_levels}")
+        levels = np.ascontiguousarray(ts.levels, LEVEL_DTYPE)
+        feats = np.ascontiguousarray(ts.features, FEATURE_DTYPE)
+        ci = np.ascontiguousarray(ts.class_idx, np.int32)
+        ti = np.ascontiguousarray(ts.template_id, np.int32)
+        _check(lib().sbm_upload_templates(self._h, ts.n_templates, _p(levels), _p(feats), len(feats), _p(ci), _p(ti)))
+        self.n_templates = ts.n_templates
+
+    def select_classes(self, class_idx: Sequence[int]):
+        a = np.asarray(list(class_idx), np.int32)
+        _check(lib().sbm_select_classes(self._h, _p(a) if len(a) else None, len(a)))
+
+    def select_range(self, first: int, count: int):
+        _check(lib().sbm_select_range(self._h, first, count))
+
+    # -- whole path -------------------------------------------------------------
+    def match(self, img: np.ndarray, threshold: float, mask: Optional[np.ndarray] = None) -> np.ndarray:
+        img, r, c, ch = _img(img)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        out = np.empty(self._cap, MATCH_DTYPE)
+        n = C.c_int64(0)
+        _check(lib().sbm_match(self._h, _p(img), r, c, c * ch, ch, _p(m), C.c_float(threshold), _p(out), self._cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def match_device(self, d_img: int, rows: int, cols: int, stride: int, channels: int, threshold: float,
+                     d_out: int, cap: int, d_count: int, stream: int = 0, d_mask: int = 0):
+        _check(lib().sbm_match_device(self._h, C.c_void_p(d_img), rows, cols, stride, channels,
+                                      C.c_void_p(d_mask) if d_mask else None, C.c_float(threshold),
+                                      C.c_void_p(d_out), cap, C.c_void_p(d_count),
+                                      C.c_void_p(stream) if stream else None))
+
+    # -- pyramid state ------------------------------------------------------------
+    def build_pyramid(self, img: np.ndarray, mask: Optional[np.ndarray] = None):
+        img, r, c, ch = _img(img)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        _check(lib().sbm_build_pyramid(self._h, _p(img), r, c, c * ch, ch, _p(m)))
+
+    def set_quantized(self, level: int, q: np.ndarray):
+        q = np.ascontiguousarray(q, np.uint8)
+        _check(lib().sbm_set_quantized(self._h, level, _p(q), q.shape[0], q.shape[1]))
+
+    def level_dims(self, level: int) -> Tuple[int, int]:
+        r, c = C.c_int32(), C.c_int32()
+        _check(lib().sbm_level_dims(self._h, level, C.byref(r), C.byref(c)))
+        return r.value, c.value
+
+    def get_quantized(self, level: int) -> np.ndarray:
+        r, c = self.level_dims(level)
+        out = np.empty((r, c), np.uint8)
+        _check(lib().sbm_get_quantized(self._h, level, _p(out)))
+        return out
+
+    def get_linear_memories(self, level: int) -> np.ndarray:
+        s = C.c_int64()
+        _check(lib().sbm_get_linear_memories(self._h, level, None, 0, C.byref(s)))
+        out = np.empty((8, s.value), np.uint8)
+        _check(lib().sbm_get_linear_memories(self._h, level, _p(out), out.nbytes, C.byref(s)))
+        return out
+
+    def match_templates(self, threshold: float) -> np.ndarray:
+        out = np.empty(self._cap, MATCH_DTYPE)
+        n = C.c_int64(0)
+        _check(lib().sbm_match_templates(self._h, C.c_float(threshold), _p(out), self._cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    # -- single reference functions -------------------------------------------
+    def quantized_orientations(self, img: np.ndarray, weak: float, want_float: bool = True):
+        img, r, c, ch = _img(img)
+        ang = np.empty((r, c), np.uint8)
+        mag = np.empty((r, c), np.float32) if want_float else None
+        ori = np.empty((r, c), np.float32) if want_float else None
+        _check(lib().sbm_quantized_orientations(self._h, _p(img), r, c, c * ch, ch, C.c_float(weak), _p(mag), _p(ang), _p(ori)))
+        return mag, ang, ori
+
+    def pyrdown(self, img: np.ndarray) -> np.ndarray:
+        img, r, c, ch = _img(img)
+        shape = (r // 2, c // 2) if img.ndim == 2 else (r // 2, c // 2, ch)
+        out = np.empty(shape, np.uint8)
+        _check(lib().sbm_pyrdown(self._h, _p(img), r, c, c * ch, ch, _p(out)))
+        return out
+
+    def spread(self, q: np.ndarray, T: int) -> np.ndarray:
+        q = np.ascontiguousarray(q, np.uint8)
+        out = np.empty_like(q)
+        _check(lib().sbm_spread(self._h, _p(q), q.shape[0], q.shape[1], T, _p(out)))
+        return out
+
+    def compute_response_maps(self, sp: np.ndarray) -> np.ndarray:
+        sp = np.ascontiguousarray(sp, np.uint8)
+        out = np.empty((8,) + sp.shape, np.uint8)
+        _check(lib().sbm_compute_response_maps(self._h, _p(sp), sp.shape[0], sp.shape[1], _p(out)))
+        return out
+
+    def linearize(self, m: np.ndarray, T: int) -> np.ndarray:
+        m = np.ascontiguousarray(m, np.uint8)
+        r, c = m.shape
+        out = np.empty((T * T, (r // T) * (c // T)), np.uint8)
+        _check(lib().sbm_linearize(self._h, _p(m), r, c, T, _p(out)))
+        return out
+
+    def similarity(self, template_index: int) -> np.ndarray:
+        lc = self.n_levels - 1
+        r, c = self.level_dims(lc)
+        T = self.T[lc]
+        out = np.empty((r // T, c // T), np.uint16)
+        _check(lib().sbm_similarity(self._h, template_index, _p(out)))
+        return out
+
+    def similarity_local(self, level: int, template_index: int, cx: int, cy: int) -> np.ndarray:
+        out = np.empty((16, 16), np.uint16)
+        _check(lib().sbm_similarity_local(self._h, level, template_index, cx, cy, _p(out)))
+        return out
+
+    # -- measurement -----------------------------------------------------------
+    def set_profiling(self, on: bool):
+        _check(lib().sbm_set_profiling(self._h, 1 if on else 0))
+
+    def timings(self) -> List[Tuple[str, float]]:
+        n = C.c_int32(0)
+        _check(lib().sbm_get_timings(self._h, None, None, 0, C.byref(n)))
+        names = (C.c_char_p * max(n.value, 1))()
+        ms = (C.c_float * max(n.value, 1))()
+        _check(lib().sbm_get_timings(self._h, names, ms, n.value, C.byref(n)))
+        return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+    def stats(self) -> Tuple[int, int]:
+        """(coarse candidates, refinement bytes) of the last template-matching call."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        _check(lib().sbm_get_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def coarse_bytes(self) -> int:
+        b = C.c_int64(0)
+        _check(lib().sbm_coarse_bytes(self._h, C.byref(b)))
+        return b.value

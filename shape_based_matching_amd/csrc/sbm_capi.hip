@@ -1,0 +1,955 @@
+// sbm_capi.hip — host side of libsbm_hip.so: the C ABI of include/sbm.h on top
+// of the kernels in sbm_kernels.h.  gfx950 only; there is no CPU fallback: every
+// entry point fails with SBM_ERR_HIP when no GPU is usable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sbm.h"
+#include "sbm_kernels.h"
+
+using namespace sbm;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(SBM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes, bool zero = false)
+    {
+        if (bytes <= cap && p) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes ? bytes : 16;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail(SBM_ERR_HIP, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        cap = want;
+        if (zero) {
+            e = hipMemset(p, 0, want);
+            if (e != hipSuccess) return fail(SBM_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+        }
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return (T*)p; }
+};
+
+struct Timing {
+    const char* name;
+    hipEvent_t a, b;
+};
+
+int64_t lm_stride_for(int rows, int cols, int T)
+{
+    int64_t W = cols / T, H = rows / T;
+    int64_t s = (int64_t)T * T * W * H + W * H + 16 * W + 16;
+    return (s + 63) / 64 * 64;
+}
+
+} // namespace
+
+struct sbm_ctx {
+    sbm_config cfg{};
+    int L = 0;
+    hipStream_t stream = nullptr;
+    int64_t cand_cap = 0;
+
+    // templates
+    int n_templates = 0;
+    int64_t n_features = 0;
+    std::vector<DevTL> h_tls;          // [n_templates][L]
+    std::vector<uint32_t> h_fxy;
+    std::vector<int32_t> h_class, h_tid;
+    std::vector<int32_t> h_active;
+    DevBuf d_tls, d_fxy, d_flabel, d_flevel, d_foff, d_class, d_tid, d_active, d_rawmin, d_rawkeep;
+    bool have_thr = false;
+    float thr_cached = 0.f;
+
+    // pyramid
+    int rows[SBM_MAX_LEVELS]{}, cols[SBM_MAX_LEVELS]{};
+    int channels = 0;
+    int levels_valid = 0; // number of levels whose linear memories are resident
+    int64_t lm_stride[SBM_MAX_LEVELS]{};
+    DevBuf d_img[SBM_MAX_LEVELS], d_mask[SBM_MAX_LEVELS], d_quant[SBM_MAX_LEVELS], d_lm[SBM_MAX_LEVELS];
+    DevBuf d_geo; // T[L], W[L], H[L] as int32 then stride[L] as int64
+    bool foff_dirty = true;
+
+    // candidates / results
+    DevBuf d_cands, d_counters, d_out, d_outcount;
+    DevBuf d_scratch;
+
+    // profiling
+    bool profiling = false;
+    std::vector<Timing> timings;
+    std::vector<float> timing_ms;
+
+    void clear_timings()
+    {
+        for (auto& t : timings) {
+            (void)hipEventDestroy(t.a);
+            (void)hipEventDestroy(t.b);
+        }
+        timings.clear();
+        timing_ms.clear();
+    }
+};
+
+namespace {
+
+struct Scope { // optional per-kernel HIP-event bracket on the launch stream
+    sbm_ctx* c;
+    hipStream_t s;
+    bool on;
+    Timing t{};
+    Scope(sbm_ctx* c_, hipStream_t s_, const char* name) : c(c_), s(s_), on(c_->profiling)
+    {
+        if (!on) return;
+        t.name = name;
+        (void)hipEventCreate(&t.a);
+        (void)hipEventCreate(&t.b);
+        (void)hipEventRecord(t.a, s);
+    }
+    ~Scope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(t.b, s);
+        c->timings.push_back(t);
+    }
+};
+
+int check_level_dims(int rows, int cols, int T)
+{
+    if (rows <= 0 || cols <= 0 || T <= 0) return fail(SBM_ERR_INVALID, "bad level geometry %dx%d T=%d", rows, cols, T);
+    if (rows % T || cols % T) // CV_Assert line2Dup.cpp:751-752
+        return fail(SBM_ERR_INVALID, "level %dx%d is not a multiple of T=%d (linearize precondition)", rows, cols, T);
+    if (((int64_t)rows * cols) % 16) // CV_Assert line2Dup.cpp:639
+        return fail(SBM_ERR_INVALID, "level %dx%d: rows*cols %% 16 != 0 (computeResponseMaps precondition)", rows, cols);
+    if ((int64_t)8 * lm_stride_for(rows, cols, T) >= (int64_t)INT32_MAX)
+        return fail(SBM_ERR_INVALID, "level %dx%d too large for 32-bit linear-memory offsets", rows, cols);
+    if (rows > 65535 || cols > 65535) return fail(SBM_ERR_INVALID, "image too large");
+    return 0;
+}
+
+// (re)allocate the per-level buffers for a level-0 geometry
+int ensure_geometry(sbm_ctx* c, int rows, int cols, int channels)
+{
+    if (channels != 1 && channels != 3) return fail(SBM_ERR_INVALID, "channels must be 1 or 3, got %d", channels);
+    bool same = c->channels == channels && c->rows[0] == rows && c->cols[0] == cols && c->d_lm[c->L - 1].p;
+    int r = rows, cc = cols;
+    for (int l = 0; l < c->L; ++l) {
+        if (l > 0) {
+            r /= 2;
+            cc /= 2;
+        }
+        if (int e = check_level_dims(r, cc, c->cfg.T[l])) return e;
+        if (c->rows[l] != r || c->cols[l] != cc) same = false;
+    }
+    if (same) return 0;
+    r = rows;
+    cc = cols;
+    for (int l = 0; l < c->L; ++l) {
+        if (l > 0) {
+            r /= 2;
+            cc /= 2;
+        }
+        c->rows[l] = r;
+        c->cols[l] = cc;
+        c->lm_stride[l] = lm_stride_for(r, cc, c->cfg.T[l]);
+        if (int e = c->d_img[l].ensure((size_t)r * cc * channels)) return e;
+        if (int e = c->d_mask[l].ensure((size_t)r * cc)) return e;
+        if (int e = c->d_quant[l].ensure((size_t)r * cc)) return e;
+        c->d_lm[l].release(); // fresh, zeroed: the tail past T*T*W*H must read as 0
+        if (int e = c->d_lm[l].ensure((size_t)8 * c->lm_stride[l], true)) return e;
+    }
+    c->channels = channels;
+    c->foff_dirty = true;
+    c->levels_valid = 0;
+    return 0;
+}
+
+int ensure_level(sbm_ctx* c, int l, int rows, int cols)
+{
+    if (int e = check_level_dims(rows, cols, c->cfg.T[l])) return e;
+    if (c->rows[l] == rows && c->cols[l] == cols && c->d_lm[l].p && c->d_quant[l].p) return 0;
+    c->rows[l] = rows;
+    c->cols[l] = cols;
+    c->lm_stride[l] = lm_stride_for(rows, cols, c->cfg.T[l]);
+    if (int e = c->d_quant[l].ensure((size_t)rows * cols)) return e;
+    c->d_lm[l].release();
+    if (int e = c->d_lm[l].ensure((size_t)8 * c->lm_stride[l], true)) return e;
+    c->foff_dirty = true;
+    return 0;
+}
+
+int upload_geo(sbm_ctx* c, hipStream_t s)
+{
+    const int L = c->L;
+    std::vector<int32_t> g(3 * SBM_MAX_LEVELS);
+    std::vector<int64_t> st(SBM_MAX_LEVELS);
+    for (int l = 0; l < L; ++l) {
+        g[l] = c->cfg.T[l];
+        g[SBM_MAX_LEVELS + l] = c->cols[l] / c->cfg.T[l];
+        g[2 * SBM_MAX_LEVELS + l] = c->rows[l] / c->cfg.T[l];
+        st[l] = c->lm_stride[l];
+    }
+    const size_t gi = g.size() * sizeof(int32_t), gs = st.size() * sizeof(int64_t);
+    if (int e = c->d_geo.ensure(gi + gs)) return e;
+    HIP_TRY(hipMemcpyAsync(c->d_geo.p, g.data(), gi, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync((char*)c->d_geo.p + gi, st.data(), gs, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s)); // host vectors go out of scope
+    return 0;
+}
+
+int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, int cols, int stride, int ch,
+                    const uint8_t* d_mask, float weak, uint8_t* d_out, float* d_mag, float* d_ori)
+{
+    dim3 grid((cols + QT_C - 1) / QT_C, (rows + QT_R - 1) / QT_R);
+    const float thr_sq = weak * weak;
+    Scope sc(c, s, "k_quantize");
+    if (ch == 1)
+        hipLaunchKernelGGL(k_quantize<1>, grid, dim3(256), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori);
+    else
+        hipLaunchKernelGGL(k_quantize<3>, grid, dim3(256), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_build_lm(sbm_ctx* c, hipStream_t s, const uint8_t* d_q, int rows, int cols, int T, uint8_t* d_lm,
+                    int64_t lm_stride)
+{
+    const int W = cols / T, H = rows / T;
+    if (T <= 8) {
+        const int tw = LM_GX * T, lw = tw + T - 1, lwp = (lw + 3) & ~3, lh = 2 * T - 1;
+        const size_t smem = (size_t)lh * lwp + (size_t)lh * tw + (size_t)T * T * LM_GX;
+        dim3 grid((W + LM_GX - 1) / LM_GX, H);
+        Scope sc(c, s, "k_build_lm");
+        hipLaunchKernelGGL(k_build_lm, grid, dim3(256), smem, s, d_q, rows, cols, T, W, H, d_lm, lm_stride);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    // large strides: unfused path through scratch (spread, 8 response maps)
+    const int64_t n = (int64_t)rows * cols;
+    if (int e = c->d_scratch.ensure((size_t)9 * n)) return e;
+    uint8_t* sp = c->d_scratch.as<uint8_t>();
+    uint8_t* maps = sp + n;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    Scope sc(c, s, "k_build_lm_unfused");
+    hipLaunchKernelGGL(k_spread, dim3(blocks), dim3(256), 0, s, d_q, rows, cols, T, sp);
+    hipLaunchKernelGGL(k_response, dim3(blocks), dim3(256), 0, s, sp, n, maps);
+    for (int o = 0; o < 8; ++o)
+        hipLaunchKernelGGL(k_linearize, dim3(blocks), dim3(256), 0, s, maps + o * n, rows, cols, T, d_lm + o * lm_stride);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// smallest raw in [0, 4nf] with score > thr (strict) / score >= thr; INT_MAX if none.
+// Evaluated with the reference's own float expression (line2Dup.cpp:1206, :1273).
+void raw_thresholds(int nf, float thr, int32_t* gt, int32_t* ge)
+{
+    *gt = *ge = INT_MAX;
+    if (nf <= 0) return;
+    const int hi = 4 * nf;
+    auto score = [nf](int raw) { return (raw * 100.f) / (4 * nf); };
+    int lo = 0, h = hi + 1; // first raw with score > thr
+    while (lo < h) {
+        int m = lo + (h - lo) / 2;
+        if (score(m) > thr) h = m;
+        else lo = m + 1;
+    }
+    if (lo <= hi) *gt = lo;
+    lo = 0;
+    h = hi + 1; // first raw with !(score < thr)
+    while (lo < h) {
+        int m = lo + (h - lo) / 2;
+        if (!(score(m) < thr)) h = m;
+        else lo = m + 1;
+    }
+    if (lo <= hi) *ge = lo;
+}
+
+int ensure_thresholds(sbm_ctx* c, float thr, hipStream_t s)
+{
+    if (c->have_thr && memcmp(&thr, &c->thr_cached, sizeof thr) == 0) return 0;
+    const size_t n = (size_t)c->n_templates * c->L;
+    std::vector<int32_t> gt(n), ge(n);
+    for (size_t i = 0; i < n; ++i) raw_thresholds(c->h_tls[i].nf, thr, &gt[i], &ge[i]);
+    if (int e = c->d_rawmin.ensure(n * 4)) return e;
+    if (int e = c->d_rawkeep.ensure(n * 4)) return e;
+    HIP_TRY(hipMemcpyAsync(c->d_rawmin.p, gt.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_rawkeep.p, ge.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->thr_cached = thr;
+    c->have_thr = true;
+    return 0;
+}
+
+int ensure_foff(sbm_ctx* c, hipStream_t s)
+{
+    if (!c->foff_dirty || c->n_features == 0) return 0;
+    if (int e = upload_geo(c, s)) return e;
+    const int32_t* g = c->d_geo.as<int32_t>();
+    const int64_t* st = (const int64_t*)((char*)c->d_geo.p + 3 * SBM_MAX_LEVELS * sizeof(int32_t));
+    const int blocks = (int)std::min<int64_t>((c->n_features + 255) / 256, 8192);
+    Scope sc(c, s, "k_prep_features");
+    hipLaunchKernelGGL(k_prep_features, dim3(blocks), dim3(256), 0, s, c->d_fxy.as<uint32_t>(),
+                       c->d_flabel.as<uint8_t>(), c->d_flevel.as<uint8_t>(), c->n_features, g,
+                       g + SBM_MAX_LEVELS, g + 2 * SBM_MAX_LEVELS, st, c->d_foff.as<int32_t>());
+    HIP_TRY(hipGetLastError());
+    c->foff_dirty = false;
+    return 0;
+}
+
+// gradient stage + linear memories for every level; d_img0 may be external
+int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride0, const uint8_t* d_mask0)
+{
+    const int ch = c->channels;
+    const uint8_t* img = d_img0;
+    int stride = stride0;
+    const uint8_t* mask = d_mask0;
+    for (int l = 0; l < c->L; ++l) {
+        if (l > 0) {
+            const int pr = c->rows[l - 1], pc = c->cols[l - 1];
+            {
+                Scope sc(c, s, "k_pyrdown");
+                const int n = c->rows[l] * c->cols[l] * ch;
+                hipLaunchKernelGGL(k_pyrdown, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, img, pr, pc, ch,
+                                   stride, c->d_img[l].as<uint8_t>());
+                HIP_TRY(hipGetLastError());
+            }
+            if (mask) {
+                Scope sc(c, s, "k_resize_mask");
+                const int n = c->rows[l] * c->cols[l];
+                hipLaunchKernelGGL(k_resize_mask, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, mask, pr, pc,
+                                   c->d_mask[l].as<uint8_t>(), c->rows[l], c->cols[l]);
+                HIP_TRY(hipGetLastError());
+                mask = c->d_mask[l].as<uint8_t>();
+            }
+            img = c->d_img[l].as<uint8_t>();
+            stride = c->cols[l] * ch;
+        }
+        if (int e = launch_quantize(c, s, img, c->rows[l], c->cols[l], stride, ch, mask, c->cfg.weak_threshold,
+                                    c->d_quant[l].as<uint8_t>(), nullptr, nullptr))
+            return e;
+        if (int e = launch_build_lm(c, s, c->d_quant[l].as<uint8_t>(), c->rows[l], c->cols[l], c->cfg.T[l],
+                                    c->d_lm[l].as<uint8_t>(), c->lm_stride[l]))
+            return e;
+    }
+    c->levels_valid = c->L;
+    return 0;
+}
+
+// matchClass over the active templates; results into d_out/d_count (device)
+int enqueue_templates(sbm_ctx* c, hipStream_t s, float threshold, sbm_match_rec* d_out, int64_t cap, int32_t* d_count)
+{
+    if (c->n_templates == 0) return fail(SBM_ERR_STATE, "no templates uploaded");
+    if (c->levels_valid < c->L) return fail(SBM_ERR_STATE, "pyramid not built (%d of %d levels)", c->levels_valid, c->L);
+    if (cap < 0 || cap > INT32_MAX) return fail(SBM_ERR_INVALID, "bad output capacity");
+    if (int e = ensure_thresholds(c, threshold, s)) return e;
+    if (int e = ensure_foff(c, s)) return e;
+    const int L = c->L, lc = L - 1;
+    int32_t* counters = c->d_counters.as<int32_t>();
+    HIP_TRY(hipMemsetAsync(counters, 0, 4 * sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(d_count, 0, 2 * sizeof(int32_t), s));
+    const int n_active = (int)c->h_active.size();
+    if (n_active > 0) {
+        const int T = c->cfg.T[lc], W = c->cols[lc] / T, H = c->rows[lc] / T;
+        const int chunks = (W * H + SIM_POS_PER_BLOCK - 1) / SIM_POS_PER_BLOCK;
+        Scope sc(c, s, "k_similarity_coarse");
+        for (int first = 0; first < n_active; first += 65535) {
+            const int cnt = std::min(65535, n_active - first);
+            hipLaunchKernelGGL(k_similarity_coarse, dim3(chunks, cnt), dim3(256), 0, s, c->d_lm[lc].as<uint8_t>(),
+                               c->rows[lc], c->cols[lc], T, W, H, L, lc, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(),
+                               c->d_foff.as<int32_t>(), c->d_active.as<int32_t>() + first, c->d_rawmin.as<int32_t>(),
+                               c->d_cands.as<Cand>(), counters, (int)c->cand_cap);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if (L == 1) {
+        Scope sc(c, s, "k_emit_coarse");
+        hipLaunchKernelGGL(k_emit_coarse, dim3(256), dim3(256), 0, s, c->d_cands.as<Cand>(), counters, (int)c->cand_cap,
+                           c->d_tls.as<DevTL>(), L, lc, c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(), d_out, d_count,
+                           (int)cap);
+        HIP_TRY(hipGetLastError());
+    }
+    for (int l = L - 2; l >= 0; --l) {
+        const int T = c->cfg.T[l], W = c->cols[l] / T;
+        Scope sc(c, s, "k_similarity_local");
+        hipLaunchKernelGGL(k_similarity_local, dim3(512), dim3(256), 0, s, c->d_lm[l].as<uint8_t>(), c->rows[l],
+                           c->cols[l], T, W, L, l, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(), c->d_foff.as<int32_t>(),
+                           c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
+                           c->d_cands.as<Cand>(), counters, (int)c->cand_cap, l == 0 ? 1 : 0, d_out, d_count, (int)cap);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, s, counters, (int)c->cand_cap, d_count);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int fetch_results(sbm_ctx* c, hipStream_t s, sbm_match_rec* out_host, int64_t cap, int64_t* n_out)
+{
+    int32_t cnt[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(cnt, c->d_outcount.p, sizeof cnt, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (n_out) *n_out = cnt[0];
+    if (cnt[1]) return fail(SBM_ERR_CAPACITY, "coarse candidate list overflowed (max_candidates=%lld)", (long long)c->cand_cap);
+    if (cnt[0] > cap || cnt[0] > c->cand_cap)
+        return fail(SBM_ERR_CAPACITY, "%d matches exceed the output capacity %lld", cnt[0], (long long)std::min<int64_t>(cap, c->cand_cap));
+    if (cnt[0] > 0) {
+        HIP_TRY(hipMemcpyAsync(out_host, c->d_out.p, (size_t)cnt[0] * sizeof(sbm_match_rec), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+void collect_timings(sbm_ctx* c)
+{
+    c->timing_ms.resize(c->timings.size());
+    for (size_t i = 0; i < c->timings.size(); ++i) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(c->timings[i].b);
+        (void)hipEventElapsedTime(&ms, c->timings[i].a, c->timings[i].b);
+        c->timing_ms[i] = ms;
+    }
+}
+
+bool feature_in_bounds(const sbm_feature& f) { return f.x >= 0 && f.y >= 0 && f.x <= 65535 && f.y <= 65535 && f.label >= 0 && f.label < 8; }
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char* sbm_last_error(void) { return g_err.c_str(); }
+int sbm_abi_version(void) { return SBM_ABI_VERSION; }
+
+int sbm_create(const sbm_config* cfg, sbm_ctx** out)
+{
+    if (!cfg || !out) return fail(SBM_ERR_INVALID, "null argument");
+    if (cfg->n_levels < 1 || cfg->n_levels > SBM_MAX_LEVELS) return fail(SBM_ERR_INVALID, "n_levels %d out of range", cfg->n_levels);
+    for (int l = 0; l < cfg->n_levels; ++l)
+        if (cfg->T[l] < 1 || cfg->T[l] > 64) return fail(SBM_ERR_INVALID, "T[%d]=%d out of range", l, cfg->T[l]);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(SBM_ERR_HIP, "no HIP device available: libsbm_hip has no CPU fallback");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(SBM_ERR_INVALID, "device_id %d out of range (%d devices)", cfg->device_id, ndev);
+    HIP_TRY(hipSetDevice(cfg->device_id));
+    sbm_ctx* c = new sbm_ctx();
+    c->cfg = *cfg;
+    c->L = cfg->n_levels;
+    c->cand_cap = cfg->max_candidates > 0 ? cfg->max_candidates : (int64_t)1 << 20;
+    if (c->cand_cap > INT32_MAX / 2) c->cand_cap = INT32_MAX / 2;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(SBM_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    int rc = 0;
+    if ((rc = c->d_cands.ensure((size_t)c->cand_cap * sizeof(Cand))) || (rc = c->d_counters.ensure(16, true)) ||
+        (rc = c->d_out.ensure((size_t)c->cand_cap * sizeof(sbm_match_rec))) || (rc = c->d_outcount.ensure(16, true))) {
+        sbm_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+void sbm_destroy(sbm_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device_id);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->clear_timings();
+    DevBuf* singles[] = {&c->d_tls, &c->d_fxy, &c->d_flabel, &c->d_flevel, &c->d_foff, &c->d_class, &c->d_tid, &c->d_active,
+                         &c->d_rawmin, &c->d_rawkeep, &c->d_geo, &c->d_cands, &c->d_counters, &c->d_out, &c->d_outcount,
+                         &c->d_scratch};
+    for (DevBuf* b : singles) b->release();
+    for (int l = 0; l < SBM_MAX_LEVELS; ++l) {
+        c->d_img[l].release();
+        c->d_mask[l].release();
+        c->d_quant[l].release();
+        c->d_lm[l].release();
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int sbm_upload_templates(sbm_ctx* c, int32_t n_templates, const sbm_template_level* levels, const sbm_feature* features,
+                         int64_t n_features, const int32_t* class_idx, const int32_t* template_id)
+{
+    if (!c || n_templates < 0 || (n_templates && !levels) || n_features < 0 || (n_features && !features))
+        return fail(SBM_ERR_INVALID, "bad template arguments");
+    if (n_features >= (int64_t)INT32_MAX) return fail(SBM_ERR_INVALID, "too many features");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    const int L = c->L;
+    std::vector<DevTL> tls((size_t)n_templates * L);
+    std::vector<uint32_t> fxy((size_t)n_features, 0);
+    std::vector<uint8_t> flabel((size_t)n_features, 0), flevel((size_t)n_features, 0);
+    for (int t = 0; t < n_templates; ++t)
+        for (int l = 0; l < L; ++l) {
+            const sbm_template_level& s = levels[(size_t)t * L + l];
+            if (s.n_features < 0 || s.n_features > SBM_MAX_FEATURES) // CV_Error line2Dup.cpp:1195, :1260
+                return fail(SBM_ERR_INVALID, "template %d level %d: feature size too large (%d >= 8192)", t, l, s.n_features);
+            if (s.feature_offset < 0 || s.feature_offset + s.n_features > n_features)
+                return fail(SBM_ERR_INVALID, "template %d level %d: feature range out of bounds", t, l);
+            for (int i = 0; i < s.n_features; ++i) {
+                const sbm_feature& f = features[s.feature_offset + i];
+                if (!feature_in_bounds(f)) // CV_DbgAssert(f.x >= 0 && f.y >= 0), line2Dup.cpp:788-789
+                    return fail(SBM_ERR_INVALID, "template %d level %d feature %d: (%d,%d,label %d) outside the supported range", t, l, i, f.x, f.y, f.label);
+                fxy[s.feature_offset + i] = (uint32_t)f.x | ((uint32_t)f.y << 16);
+                flabel[s.feature_offset + i] = (uint8_t)f.label;
+                flevel[s.feature_offset + i] = (uint8_t)l;
+            }
+            DevTL d;
+            d.width = s.width;
+            d.height = s.height;
+            d.nf = s.n_features;
+            d.feat_off = (int32_t)s.feature_offset;
+            tls[(size_t)t * L + l] = d;
+        }
+    std::vector<int32_t> cls(n_templates), tid(n_templates);
+    for (int t = 0; t < n_templates; ++t) {
+        cls[t] = class_idx ? class_idx[t] : 0;
+        tid[t] = template_id ? template_id[t] : t;
+    }
+    int rc = 0;
+    if ((rc = c->d_tls.ensure(tls.size() * sizeof(DevTL))) || (rc = c->d_fxy.ensure(fxy.size() * 4)) ||
+        (rc = c->d_flabel.ensure(flabel.size())) || (rc = c->d_flevel.ensure(flevel.size())) ||
+        (rc = c->d_foff.ensure(fxy.size() * 4)) || (rc = c->d_class.ensure(cls.size() * 4)) ||
+        (rc = c->d_tid.ensure(tid.size() * 4)))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!tls.empty()) HIP_TRY(hipMemcpy(c->d_tls.p, tls.data(), tls.size() * sizeof(DevTL), hipMemcpyHostToDevice));
+    if (!fxy.empty()) {
+        HIP_TRY(hipMemcpy(c->d_fxy.p, fxy.data(), fxy.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_flabel.p, flabel.data(), flabel.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_flevel.p, flevel.data(), flevel.size(), hipMemcpyHostToDevice));
+    }
+    if (n_templates) {
+        HIP_TRY(hipMemcpy(c->d_class.p, cls.data(), cls.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_tid.p, tid.data(), tid.size() * 4, hipMemcpyHostToDevice));
+    }
+    c->n_templates = n_templates;
+    c->n_features = n_features;
+    c->h_tls.swap(tls);
+    c->h_fxy.swap(fxy);
+    c->h_class.swap(cls);
+    c->h_tid.swap(tid);
+    c->have_thr = false;
+    c->foff_dirty = true;
+    return sbm_select_classes(c, nullptr, 0);
+}
+
+static int set_active(sbm_ctx* c, std::vector<int32_t>& act)
+{
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    if (int e = c->d_active.ensure(std::max<size_t>(act.size(), 1) * 4)) return e;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!act.empty()) HIP_TRY(hipMemcpy(c->d_active.p, act.data(), act.size() * 4, hipMemcpyHostToDevice));
+    c->h_active.swap(act);
+    return 0;
+}
+
+int sbm_select_classes(sbm_ctx* c, const int32_t* class_idx, int32_t n)
+{
+    if (!c || n < 0 || (n && !class_idx)) return fail(SBM_ERR_INVALID, "bad class selection");
+    std::vector<int32_t> act;
+    if (n == 0) {
+        act.resize(c->n_templates);
+        for (int t = 0; t < c->n_templates; ++t) act[t] = t;
+    } else {
+        // class_ids order, then template order: the order matchClass is called in (line2Dup.cpp:1134-1139)
+        for (int i = 0; i < n; ++i)
+            for (int t = 0; t < c->n_templates; ++t)
+                if (c->h_class[t] == class_idx[i]) act.push_back(t);
+    }
+    return set_active(c, act);
+}
+
+int sbm_select_range(sbm_ctx* c, int32_t first, int32_t count)
+{
+    if (!c || first < 0 || count < 0 || first + count > c->n_templates) return fail(SBM_ERR_INVALID, "bad template range");
+    std::vector<int32_t> act(count);
+    for (int i = 0; i < count; ++i) act[i] = first + i;
+    return set_active(c, act);
+}
+
+int sbm_match_device(sbm_ctx* c, const void* d_img, int32_t rows, int32_t cols, int32_t stride, int32_t channels,
+                     const void* d_mask, float threshold, void* d_out, int64_t cap, void* d_count, void* stream)
+{
+    if (!c || !d_img || !d_out || !d_count) return fail(SBM_ERR_INVALID, "null argument");
+    if (stride < cols * channels) return fail(SBM_ERR_INVALID, "stride %d < cols*channels", stride);
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (int e = ensure_geometry(c, rows, cols, channels)) return e;
+    if (c->profiling) c->clear_timings();
+    if (int e = enqueue_pyramid(c, s, (const uint8_t*)d_img, stride, (const uint8_t*)d_mask)) return e;
+    return enqueue_templates(c, s, threshold, (sbm_match_rec*)d_out, cap, (int32_t*)d_count);
+}
+
+static int upload_image(sbm_ctx* c, const uint8_t* img, int rows, int cols, int stride, int ch, const uint8_t* mask)
+{
+    if (!img) return fail(SBM_ERR_INVALID, "null image");
+    if (stride < cols * ch) return fail(SBM_ERR_INVALID, "stride %d < cols*channels", stride);
+    if (int e = ensure_geometry(c, rows, cols, ch)) return e;
+    HIP_TRY(hipMemcpy2DAsync(c->d_img[0].p, (size_t)cols * ch, img, stride, (size_t)cols * ch, rows, hipMemcpyHostToDevice, c->stream));
+    if (mask) HIP_TRY(hipMemcpyAsync(c->d_mask[0].p, mask, (size_t)rows * cols, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int sbm_match(sbm_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t channels,
+              const uint8_t* mask, float threshold, sbm_match_rec* out, int64_t cap, int64_t* n_out)
+{
+    if (!c || (!out && cap > 0) || !n_out) return fail(SBM_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    if (c->profiling) c->clear_timings();
+    if (int e = upload_image(c, img, rows, cols, stride, channels, mask)) return e;
+    if (int e = enqueue_pyramid(c, c->stream, c->d_img[0].as<uint8_t>(), cols * channels, mask ? c->d_mask[0].as<uint8_t>() : nullptr)) return e;
+    if (int e = enqueue_templates(c, c->stream, threshold, c->d_out.as<sbm_match_rec>(), c->cand_cap, c->d_outcount.as<int32_t>())) return e;
+    int rc = fetch_results(c, c->stream, out, cap, n_out);
+    if (c->profiling) collect_timings(c);
+    return rc;
+}
+
+static int rec_cmp(const sbm_match_rec& x, const sbm_match_rec& y)
+{
+    if (x.similarity != y.similarity) return x.similarity > y.similarity ? -1 : 1;
+    if (x.template_id != y.template_id) return x.template_id < y.template_id ? -1 : 1;
+    if (x.class_idx != y.class_idx) return x.class_idx < y.class_idx ? -1 : 1;
+    if (x.y != y.y) return x.y < y.y ? -1 : 1;
+    if (x.x != y.x) return x.x < y.x ? -1 : 1;
+    return 0;
+}
+
+int64_t sbm_canonicalize(sbm_match_rec* recs, int64_t n)
+{
+    if (!recs || n <= 0) return 0;
+    std::sort(recs, recs + n, [](const sbm_match_rec& a, const sbm_match_rec& b) { return rec_cmp(a, b) < 0; });
+    int64_t k = 1;
+    for (int64_t i = 1; i < n; ++i)
+        if (rec_cmp(recs[i], recs[k - 1]) != 0) recs[k++] = recs[i];
+    return k;
+}
+
+int sbm_build_pyramid(sbm_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t channels,
+                      const uint8_t* mask)
+{
+    if (!c) return fail(SBM_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    if (c->profiling) c->clear_timings();
+    if (int e = upload_image(c, img, rows, cols, stride, channels, mask)) return e;
+    if (int e = enqueue_pyramid(c, c->stream, c->d_img[0].as<uint8_t>(), cols * channels, mask ? c->d_mask[0].as<uint8_t>() : nullptr)) return e;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->profiling) collect_timings(c);
+    return 0;
+}
+
+int sbm_set_quantized(sbm_ctx* c, int32_t level, const uint8_t* q, int32_t rows, int32_t cols)
+{
+    if (!c || !q || level < 0 || level >= c->L) return fail(SBM_ERR_INVALID, "bad level");
+    if (level > c->levels_valid) return fail(SBM_ERR_STATE, "levels must be set from 0 upwards");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    if (int e = ensure_level(c, level, rows, cols)) return e;
+    if (c->profiling && level == 0) c->clear_timings();
+    HIP_TRY(hipMemcpyAsync(c->d_quant[level].p, q, (size_t)rows * cols, hipMemcpyHostToDevice, c->stream));
+    if (int e = launch_build_lm(c, c->stream, c->d_quant[level].as<uint8_t>(), rows, cols, c->cfg.T[level],
+                                c->d_lm[level].as<uint8_t>(), c->lm_stride[level]))
+        return e;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->levels_valid = std::max(c->levels_valid, level + 1);
+    if (c->profiling) collect_timings(c);
+    return 0;
+}
+
+int sbm_get_quantized(sbm_ctx* c, int32_t level, uint8_t* out)
+{
+    if (!c || !out || level < 0 || level >= c->levels_valid) return fail(SBM_ERR_STATE, "level not resident");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->d_quant[level].p, (size_t)c->rows[level] * c->cols[level], hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sbm_get_linear_memories(sbm_ctx* c, int32_t level, uint8_t* out, int64_t cap_bytes, int64_t* lm_stride)
+{
+    if (!c || level < 0 || level >= c->levels_valid) return fail(SBM_ERR_STATE, "level not resident");
+    if (lm_stride) *lm_stride = c->lm_stride[level];
+    if (!out) return 0;
+    const int64_t need = 8 * c->lm_stride[level];
+    if (cap_bytes < need) return fail(SBM_ERR_CAPACITY, "need %lld bytes", (long long)need);
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->d_lm[level].p, (size_t)need, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sbm_level_dims(sbm_ctx* c, int32_t level, int32_t* rows, int32_t* cols)
+{
+    if (!c || level < 0 || level >= c->levels_valid) return fail(SBM_ERR_STATE, "level not resident");
+    if (rows) *rows = c->rows[level];
+    if (cols) *cols = c->cols[level];
+    return 0;
+}
+
+int sbm_match_templates(sbm_ctx* c, float threshold, sbm_match_rec* out, int64_t cap, int64_t* n_out)
+{
+    if (!c || (!out && cap > 0) || !n_out) return fail(SBM_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    if (c->profiling) c->clear_timings();
+    if (int e = enqueue_templates(c, c->stream, threshold, c->d_out.as<sbm_match_rec>(), c->cand_cap, c->d_outcount.as<int32_t>())) return e;
+    int rc = fetch_results(c, c->stream, out, cap, n_out);
+    if (c->profiling) collect_timings(c);
+    return rc;
+}
+
+// ---- stage entry points -----------------------------------------------------
+int sbm_quantized_orientations(sbm_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t ch,
+                               float weak, float* magnitude, uint8_t* angle, float* angle_ori)
+{
+    if (!c || !img || !angle || rows < 3 || cols < 3) return fail(SBM_ERR_INVALID, "bad argument");
+    if (ch != 1 && ch != 3) return fail(SBM_ERR_INVALID, "channels must be 1 or 3");
+    if (stride < cols * ch) return fail(SBM_ERR_INVALID, "stride too small");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    const size_t npx = (size_t)rows * cols;
+    DevBuf d_in, d_q, d_mag, d_ori;
+    int rc = 0;
+    if ((rc = d_in.ensure(npx * ch)) || (rc = d_q.ensure(npx)) || (magnitude && (rc = d_mag.ensure(npx * 4))) ||
+        (angle_ori && (rc = d_ori.ensure(npx * 4))))
+        goto done;
+    if (hipMemcpy2D(d_in.p, (size_t)cols * ch, img, stride, (size_t)cols * ch, rows, hipMemcpyHostToDevice) != hipSuccess) {
+        rc = fail(SBM_ERR_HIP, "image upload failed");
+        goto done;
+    }
+    if ((rc = launch_quantize(c, c->stream, d_in.as<uint8_t>(), rows, cols, cols * ch, ch, nullptr, weak, d_q.as<uint8_t>(),
+                              magnitude ? d_mag.as<float>() : nullptr, angle_ori ? d_ori.as<float>() : nullptr)))
+        goto done;
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(angle, d_q.p, npx, hipMemcpyDeviceToHost) != hipSuccess ||
+        (magnitude && hipMemcpy(magnitude, d_mag.p, npx * 4, hipMemcpyDeviceToHost) != hipSuccess) ||
+        (angle_ori && hipMemcpy(angle_ori, d_ori.p, npx * 4, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = fail(SBM_ERR_HIP, "quantize kernel or download failed: %s", hipGetErrorString(hipGetLastError()));
+done:
+    d_in.release();
+    d_q.release();
+    d_mag.release();
+    d_ori.release();
+    return rc;
+}
+
+int sbm_pyrdown(sbm_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t ch, uint8_t* out)
+{
+    if (!c || !img || !out || rows < 2 || cols < 2 || ch < 1 || ch > 4) return fail(SBM_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    DevBuf d_in, d_out;
+    int rc = 0;
+    const size_t nout = (size_t)(rows / 2) * (cols / 2) * ch;
+    if ((rc = d_in.ensure((size_t)rows * cols * ch)) || (rc = d_out.ensure(nout))) goto done;
+    if (hipMemcpy2D(d_in.p, (size_t)cols * ch, img, stride, (size_t)cols * ch, rows, hipMemcpyHostToDevice) != hipSuccess) {
+        rc = fail(SBM_ERR_HIP, "upload failed");
+        goto done;
+    }
+    hipLaunchKernelGGL(k_pyrdown, dim3((unsigned)std::min<size_t>((nout + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                       d_in.as<uint8_t>(), rows, cols, ch, cols * ch, d_out.as<uint8_t>());
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, d_out.p, nout, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(SBM_ERR_HIP, "pyrdown failed: %s", hipGetErrorString(hipGetLastError()));
+done:
+    d_in.release();
+    d_out.release();
+    return rc;
+}
+
+int sbm_spread(sbm_ctx* c, const uint8_t* src, int32_t rows, int32_t cols, int32_t T, uint8_t* dst)
+{
+    if (!c || !src || !dst || rows < 1 || cols < 1 || T < 1) return fail(SBM_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    const size_t n = (size_t)rows * cols;
+    DevBuf a, b;
+    int rc = 0;
+    if ((rc = a.ensure(n)) || (rc = b.ensure(n))) goto done;
+    if (hipMemcpy(a.p, src, n, hipMemcpyHostToDevice) != hipSuccess) {
+        rc = fail(SBM_ERR_HIP, "upload failed");
+        goto done;
+    }
+    hipLaunchKernelGGL(k_spread, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                       a.as<uint8_t>(), rows, cols, T, b.as<uint8_t>());
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(dst, b.p, n, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(SBM_ERR_HIP, "spread failed: %s", hipGetErrorString(hipGetLastError()));
+done:
+    a.release();
+    b.release();
+    return rc;
+}
+
+int sbm_compute_response_maps(sbm_ctx* c, const uint8_t* spread, int32_t rows, int32_t cols, uint8_t* maps)
+{
+    if (!c || !spread || !maps || rows < 1 || cols < 1) return fail(SBM_ERR_INVALID, "bad argument");
+    if (((int64_t)rows * cols) % 16) return fail(SBM_ERR_INVALID, "rows*cols %% 16 != 0 (line2Dup.cpp:639)");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    const size_t n = (size_t)rows * cols;
+    DevBuf a, b;
+    int rc = 0;
+    if ((rc = a.ensure(n)) || (rc = b.ensure(8 * n))) goto done;
+    if (hipMemcpy(a.p, spread, n, hipMemcpyHostToDevice) != hipSuccess) {
+        rc = fail(SBM_ERR_HIP, "upload failed");
+        goto done;
+    }
+    hipLaunchKernelGGL(k_response, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                       a.as<uint8_t>(), (int64_t)n, b.as<uint8_t>());
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(maps, b.p, 8 * n, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(SBM_ERR_HIP, "response failed: %s", hipGetErrorString(hipGetLastError()));
+done:
+    a.release();
+    b.release();
+    return rc;
+}
+
+int sbm_linearize(sbm_ctx* c, const uint8_t* map, int32_t rows, int32_t cols, int32_t T, uint8_t* lm)
+{
+    if (!c || !map || !lm || rows < 1 || cols < 1 || T < 1) return fail(SBM_ERR_INVALID, "bad argument");
+    if (rows % T || cols % T) return fail(SBM_ERR_INVALID, "rows/cols not a multiple of T (line2Dup.cpp:751-752)");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    const size_t n = (size_t)rows * cols;
+    DevBuf a, b;
+    int rc = 0;
+    if ((rc = a.ensure(n)) || (rc = b.ensure(n))) goto done;
+    if (hipMemcpy(a.p, map, n, hipMemcpyHostToDevice) != hipSuccess) {
+        rc = fail(SBM_ERR_HIP, "upload failed");
+        goto done;
+    }
+    hipLaunchKernelGGL(k_linearize, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                       a.as<uint8_t>(), rows, cols, T, b.as<uint8_t>());
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(lm, b.p, n, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(SBM_ERR_HIP, "linearize failed: %s", hipGetErrorString(hipGetLastError()));
+done:
+    a.release();
+    b.release();
+    return rc;
+}
+
+int sbm_similarity(sbm_ctx* c, int32_t t, uint16_t* dst)
+{
+    if (!c || !dst || t < 0 || t >= c->n_templates) return fail(SBM_ERR_INVALID, "bad template index");
+    if (c->levels_valid < c->L) return fail(SBM_ERR_STATE, "pyramid not built");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    if (int e = ensure_foff(c, c->stream)) return e;
+    const int lc = c->L - 1, T = c->cfg.T[lc], W = c->cols[lc] / T, H = c->rows[lc] / T;
+    DevBuf d;
+    if (int e = d.ensure((size_t)W * H * 2)) return e;
+    hipLaunchKernelGGL(k_similarity_map, dim3((W * H + SIM_POS_PER_BLOCK - 1) / SIM_POS_PER_BLOCK), dim3(256), 0, c->stream,
+                       c->d_lm[lc].as<uint8_t>(), c->rows[lc], c->cols[lc], T, W, H, c->h_tls[(size_t)t * c->L + lc],
+                       c->d_fxy.as<uint32_t>(), c->d_foff.as<int32_t>(), d.as<uint16_t>());
+    int rc = 0;
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(dst, d.p, (size_t)W * H * 2, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(SBM_ERR_HIP, "similarity failed: %s", hipGetErrorString(hipGetLastError()));
+    d.release();
+    return rc;
+}
+
+int sbm_similarity_local(sbm_ctx* c, int32_t level, int32_t t, int32_t cx, int32_t cy, uint16_t* dst)
+{
+    if (!c || !dst || t < 0 || t >= c->n_templates || level < 0 || level >= c->L) return fail(SBM_ERR_INVALID, "bad argument");
+    if (c->levels_valid <= level) return fail(SBM_ERR_STATE, "level not resident");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    if (int e = ensure_foff(c, c->stream)) return e;
+    const int T = c->cfg.T[level], W = c->cols[level] / T;
+    DevBuf d;
+    if (int e = d.ensure(512)) return e;
+    hipLaunchKernelGGL(k_similarity_local_patch, dim3(1), dim3(64), 0, c->stream, c->d_lm[level].as<uint8_t>(), c->rows[level],
+                       c->cols[level], T, W, c->h_tls[(size_t)t * c->L + level], c->d_fxy.as<uint32_t>(),
+                       c->d_foff.as<int32_t>(), cx, cy, d.as<uint16_t>());
+    int rc = 0;
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(dst, d.p, 512, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(SBM_ERR_HIP, "similarity_local failed: %s", hipGetErrorString(hipGetLastError()));
+    d.release();
+    return rc;
+}
+
+int sbm_set_profiling(sbm_ctx* c, int32_t enabled)
+{
+    if (!c) return fail(SBM_ERR_INVALID, "null context");
+    c->profiling = enabled != 0;
+    if (!c->profiling) c->clear_timings();
+    return 0;
+}
+
+int sbm_get_timings(sbm_ctx* c, const char** names, float* ms, int32_t cap, int32_t* n)
+{
+    if (!c || !n) return fail(SBM_ERR_INVALID, "null argument");
+    if (c->timing_ms.size() != c->timings.size()) collect_timings(c);
+    *n = (int32_t)c->timings.size();
+    for (int i = 0; i < *n && i < cap; ++i) {
+        if (names) names[i] = c->timings[i].name;
+        if (ms) ms[i] = c->timing_ms[i];
+    }
+    return 0;
+}
+
+int sbm_get_stats(sbm_ctx* c, int64_t* n_candidates, int64_t* refine_bytes)
+{
+    if (!c) return fail(SBM_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    HIP_TRY(hipDeviceSynchronize());
+    int32_t h[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(h, c->d_counters.p, sizeof h, hipMemcpyDeviceToHost));
+    if (n_candidates) *n_candidates = h[0];
+    if (refine_bytes) {
+        uint64_t b;
+        memcpy(&b, &h[2], sizeof b);
+        *refine_bytes = (int64_t)b;
+    }
+    return 0;
+}
+
+int sbm_coarse_bytes(sbm_ctx* c, int64_t* bytes)
+{
+    if (!c || !bytes) return fail(SBM_ERR_INVALID, "null argument");
+    if (c->levels_valid < c->L) return fail(SBM_ERR_STATE, "pyramid not built");
+    const int lc = c->L - 1, T = c->cfg.T[lc], W = c->cols[lc] / T, H = c->rows[lc] / T;
+    int64_t total = 0;
+    for (int32_t t : c->h_active) {
+        const DevTL& tl = c->h_tls[(size_t)t * c->L + lc];
+        const int wf = (tl.width - 1) / T + 1, hf = (tl.height - 1) / T + 1;
+        const int npos = (H - hf) * W + (W - wf) + 1;
+        if (npos <= 0) continue;
+        for (int i = 0; i < tl.nf; ++i) {
+            const uint32_t xy = c->h_fxy[tl.feat_off + i];
+            if ((int)(xy & 0xffff) < c->cols[lc] && (int)(xy >> 16) < c->rows[lc]) total += npos;
+        }
+    }
+    *bytes = total;
+    return 0;
+}
+
+} // extern "C"

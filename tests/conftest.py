@@ -1,0 +1,69 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REFERENCE = "/root/reference"  # exists only in the authoring container
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+
+    O.build()
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def case1(golden):
+    from shape_based_matching_amd.templates import TemplateSet
+
+    return {
+        "templates": TemplateSet.load_npz(os.path.join(golden, "case1_templates.npz")),
+        "train": np.load(os.path.join(golden, "case1_train_bgr.npz"))["bgr"],
+        "test": np.load(os.path.join(golden, "case1_test_bgr.npz"))["bgr"],
+    }
+
+
+@pytest.fixture(scope="session")
+def case2(golden):
+    from shape_based_matching_amd.templates import TemplateSet
+
+    return {
+        "templates": TemplateSet.load_npz(os.path.join(golden, "case2_templates.npz")),
+        "train": np.load(os.path.join(golden, "case2_train_bgr.npz"))["bgr"],
+        "test": np.load(os.path.join(golden, "case2_test_bgr.npz"))["bgr"],
+    }
+
+
+@pytest.fixture()
+def ctx_factory():
+    """Creates GPU contexts through the C ABI and closes them afterwards."""
+    from shape_based_matching_amd import capi
+
+    made = []
+
+    def make(T=(4, 8), weak=30.0, max_candidates=0):
+        c = capi.Context(T=T, weak_threshold=weak, device_id=0, max_candidates=max_candidates)
+        made.append(c)
+        return c
+
+    yield make
+    for c in made:
+        c.close()
