@@ -149,8 +149,8 @@ def test_invalid_arguments_fail_loudly(ctx_factory):
     from shape_based_matching_amd import capi
 
     ctx = ctx_factory()
-    with pytest.raises(capi.SbmError):  # 100 % 8 != 0 (linearize precondition, :751-752)
-        ctx.set_quantized(0, np.zeros((100, 100), np.uint8))
+    with pytest.raises(capi.SbmError):  # 102 % 4 != 0 (linearize precondition, :751-752)
+        ctx.set_quantized(0, np.zeros((100, 102), np.uint8))
     ts = from_pyramids([[{"width": 10, "height": 10, "features": np.zeros((8192, 3), np.int32)}] * 2])
     with pytest.raises(capi.SbmError):  # feature size too large (:1195)
         ctx.upload_templates(ts)
