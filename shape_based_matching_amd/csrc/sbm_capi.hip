@@ -235,15 +235,20 @@ int upload_geo(sbm_ctx* c, hipStream_t s)
 }
 
 int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, int cols, int stride, int ch,
-                    const uint8_t* d_mask, float weak, uint8_t* d_out, float* d_mag, float* d_ori)
+                    const uint8_t* d_mask, float weak, uint8_t* d_out, float* d_mag, float* d_ori, uint8_t* d_pyr)
 {
     dim3 grid((cols + QT_C - 1) / QT_C, (rows + QT_R - 1) / QT_R);
     const float thr_sq = weak * weak;
+    const bool wf = d_mag || d_ori;
     Scope sc(c, s, "k_quantize");
-    if (ch == 1)
-        hipLaunchKernelGGL(k_quantize<1>, grid, dim3(256), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori);
+    if (ch == 1 && !wf)
+        hipLaunchKernelGGL((k_quantize<1, false>), grid, dim3(256), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
+    else if (ch == 1)
+        hipLaunchKernelGGL((k_quantize<1, true>), grid, dim3(256), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
+    else if (!wf)
+        hipLaunchKernelGGL((k_quantize<3, false>), grid, dim3(256), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
     else
-        hipLaunchKernelGGL(k_quantize<3>, grid, dim3(256), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori);
+        hipLaunchKernelGGL((k_quantize<3, true>), grid, dim3(256), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -252,6 +257,16 @@ int launch_build_lm(sbm_ctx* c, hipStream_t s, const uint8_t* d_q, int rows, int
                     int64_t lm_stride)
 {
     const int W = cols / T, H = rows / T;
+    if ((T == 4 || T == 8) && (W & 3) == 0 && (cols & 15) == 0 && (((uintptr_t)d_q) & 15) == 0) {
+        const int64_t items = (int64_t)rows * (W >> 2);
+        Scope sc(c, s, "k_build_lm");
+        if (T == 4)
+            hipLaunchKernelGGL(k_build_lm_rows<4>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, d_q, rows, cols, W, H, d_lm, lm_stride);
+        else
+            hipLaunchKernelGGL(k_build_lm_rows<8>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, d_q, rows, cols, W, H, d_lm, lm_stride);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (T <= 8) {
         const int tw = LM_GX * T, lw = tw + T - 1, lwp = (lw + 3) & ~3, lh = 2 * T - 1;
         const size_t smem = (size_t)lh * lwp + (size_t)lh * tw + (size_t)T * T * LM_GX;
@@ -343,13 +358,7 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
     for (int l = 0; l < c->L; ++l) {
         if (l > 0) {
             const int pr = c->rows[l - 1], pc = c->cols[l - 1];
-            {
-                Scope sc(c, s, "k_pyrdown");
-                const int n = c->rows[l] * c->cols[l] * ch;
-                hipLaunchKernelGGL(k_pyrdown, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, img, pr, pc, ch,
-                                   stride, c->d_img[l].as<uint8_t>());
-                HIP_TRY(hipGetLastError());
-            }
+            // the image of level l was produced by level l-1's quantize launch (fused cv::pyrDown)
             if (mask) {
                 Scope sc(c, s, "k_resize_mask");
                 const int n = c->rows[l] * c->cols[l];
@@ -362,7 +371,8 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
             stride = c->cols[l] * ch;
         }
         if (int e = launch_quantize(c, s, img, c->rows[l], c->cols[l], stride, ch, mask, c->cfg.weak_threshold,
-                                    c->d_quant[l].as<uint8_t>(), nullptr, nullptr))
+                                    c->d_quant[l].as<uint8_t>(), nullptr, nullptr,
+                                    l + 1 < c->L ? c->d_img[l + 1].as<uint8_t>() : nullptr))
             return e;
         if (int e = launch_build_lm(c, s, c->d_quant[l].as<uint8_t>(), c->rows[l], c->cols[l], c->cfg.T[l],
                                     c->d_lm[l].as<uint8_t>(), c->lm_stride[l]))
@@ -382,17 +392,16 @@ int enqueue_templates(sbm_ctx* c, hipStream_t s, float threshold, sbm_match_rec*
     if (int e = ensure_foff(c, s)) return e;
     const int L = c->L, lc = L - 1;
     int32_t* counters = c->d_counters.as<int32_t>();
-    HIP_TRY(hipMemsetAsync(counters, 0, 4 * sizeof(int32_t), s));
-    HIP_TRY(hipMemsetAsync(d_count, 0, 2 * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s, counters, d_count);
     const int n_active = (int)c->h_active.size();
     if (n_active > 0) {
         const int T = c->cfg.T[lc], W = c->cols[lc] / T, H = c->rows[lc] / T;
-        const int chunks = (W * H + SIM_POS_PER_BLOCK - 1) / SIM_POS_PER_BLOCK;
+        const int chunks = (W * H + COARSE_POS_PER_BLOCK - 1) / COARSE_POS_PER_BLOCK;
         Scope sc(c, s, "k_similarity_coarse");
         for (int first = 0; first < n_active; first += 65535) {
             const int cnt = std::min(65535, n_active - first);
-            hipLaunchKernelGGL(k_similarity_coarse, dim3(chunks, cnt), dim3(256), 0, s, c->d_lm[lc].as<uint8_t>(),
-                               c->rows[lc], c->cols[lc], T, W, H, L, lc, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(),
+            hipLaunchKernelGGL(k_similarity_coarse, dim3(chunks, cnt), dim3(64), 0, s, c->d_lm[lc].as<uint8_t>(),
+                               c->lm_stride[lc], c->rows[lc], c->cols[lc], T, W, H, L, lc, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(),
                                c->d_foff.as<int32_t>(), c->d_active.as<int32_t>() + first, c->d_rawmin.as<int32_t>(),
                                c->d_cands.as<Cand>(), counters, (int)c->cand_cap);
         }
@@ -406,16 +415,14 @@ int enqueue_templates(sbm_ctx* c, hipStream_t s, float threshold, sbm_match_rec*
         HIP_TRY(hipGetLastError());
     }
     for (int l = L - 2; l >= 0; --l) {
-        const int T = c->cfg.T[l], W = c->cols[l] / T;
+        const int T = c->cfg.T[l], W = c->cols[l] / T, H = c->rows[l] / T;
         Scope sc(c, s, "k_similarity_local");
-        hipLaunchKernelGGL(k_similarity_local, dim3(512), dim3(256), 0, s, c->d_lm[l].as<uint8_t>(), c->rows[l],
-                           c->cols[l], T, W, L, l, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(), c->d_foff.as<int32_t>(),
+        hipLaunchKernelGGL(k_similarity_local, dim3(1024), dim3(256), 0, s, c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
+                           c->rows[l], c->cols[l], T, W, H, L, l, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(), c->d_foff.as<int32_t>(),
                            c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
                            c->d_cands.as<Cand>(), counters, (int)c->cand_cap, l == 0 ? 1 : 0, d_out, d_count, (int)cap);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, s, counters, (int)c->cand_cap, d_count);
-    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -754,7 +761,7 @@ int sbm_quantized_orientations(sbm_ctx* c, const uint8_t* img, int32_t rows, int
         goto done;
     }
     if ((rc = launch_quantize(c, c->stream, d_in.as<uint8_t>(), rows, cols, cols * ch, ch, nullptr, weak, d_q.as<uint8_t>(),
-                              magnitude ? d_mag.as<float>() : nullptr, angle_ori ? d_ori.as<float>() : nullptr)))
+                              magnitude ? d_mag.as<float>() : nullptr, angle_ori ? d_ori.as<float>() : nullptr, nullptr)))
         goto done;
     if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(angle, d_q.p, npx, hipMemcpyDeviceToHost) != hipSuccess ||
         (magnitude && hipMemcpy(magnitude, d_mag.p, npx * 4, hipMemcpyDeviceToHost) != hipSuccess) ||
@@ -780,7 +787,7 @@ int sbm_pyrdown(sbm_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int3
         rc = fail(SBM_ERR_HIP, "upload failed");
         goto done;
     }
-    hipLaunchKernelGGL(k_pyrdown, dim3((unsigned)std::min<size_t>((nout + 255) / 256, 4096)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(k_pyrdown, dim3((unsigned)std::min<size_t>((nout / ch + 255) / 256, 4096)), dim3(256), 0, c->stream,
                        d_in.as<uint8_t>(), rows, cols, ch, cols * ch, d_out.as<uint8_t>());
     if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, d_out.p, nout, hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(SBM_ERR_HIP, "pyrdown failed: %s", hipGetErrorString(hipGetLastError()));
@@ -868,7 +875,7 @@ int sbm_similarity(sbm_ctx* c, int32_t t, uint16_t* dst)
     DevBuf d;
     if (int e = d.ensure((size_t)W * H * 2)) return e;
     hipLaunchKernelGGL(k_similarity_map, dim3((W * H + SIM_POS_PER_BLOCK - 1) / SIM_POS_PER_BLOCK), dim3(256), 0, c->stream,
-                       c->d_lm[lc].as<uint8_t>(), c->rows[lc], c->cols[lc], T, W, H, c->h_tls[(size_t)t * c->L + lc],
+                       c->d_lm[lc].as<uint8_t>(), c->lm_stride[lc], c->rows[lc], c->cols[lc], T, W, H, c->h_tls[(size_t)t * c->L + lc],
                        c->d_fxy.as<uint32_t>(), c->d_foff.as<int32_t>(), d.as<uint16_t>());
     int rc = 0;
     if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(dst, d.p, (size_t)W * H * 2, hipMemcpyDeviceToHost) != hipSuccess)
@@ -883,11 +890,11 @@ int sbm_similarity_local(sbm_ctx* c, int32_t level, int32_t t, int32_t cx, int32
     if (c->levels_valid <= level) return fail(SBM_ERR_STATE, "level not resident");
     HIP_TRY(hipSetDevice(c->cfg.device_id));
     if (int e = ensure_foff(c, c->stream)) return e;
-    const int T = c->cfg.T[level], W = c->cols[level] / T;
+    const int T = c->cfg.T[level], W = c->cols[level] / T, H = c->rows[level] / T;
     DevBuf d;
     if (int e = d.ensure(512)) return e;
-    hipLaunchKernelGGL(k_similarity_local_patch, dim3(1), dim3(64), 0, c->stream, c->d_lm[level].as<uint8_t>(), c->rows[level],
-                       c->cols[level], T, W, c->h_tls[(size_t)t * c->L + level], c->d_fxy.as<uint32_t>(),
+    hipLaunchKernelGGL(k_similarity_local_patch, dim3(1), dim3(256), 0, c->stream, c->d_lm[level].as<uint8_t>(),
+                       c->lm_stride[level], c->rows[level], c->cols[level], T, W, H, c->h_tls[(size_t)t * c->L + level], c->d_fxy.as<uint32_t>(),
                        c->d_foff.as<int32_t>(), cx, cy, d.as<uint16_t>());
     int rc = 0;
     if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(dst, d.p, 512, hipMemcpyDeviceToHost) != hipSuccess)

@@ -42,6 +42,7 @@ __device__ __forceinline__ int reflect101(int p, int len)
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __device__ __forceinline__ uint32_t ld_u32_any(const uint8_t* p) { return *(const u32_unaligned*)p; }
+struct __attribute__((aligned(4))) u128_a4 { uint32_t x, y, z, w; }; // 16-byte load at 4-byte alignment
 
 // ---------------------------------------------------------------------------
 // Gradient stage
@@ -79,149 +80,325 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
-// One block = one 16x64 output tile.  Source tile -> LDS, separable 7-tap
-// fixed-point Gaussian through LDS, Sobel + magnitude + orientation bin into
-// LDS, 3x3 majority vote, one-hot bytes out (4 per lane).
-template <int CH>
+// ---------------------------------------------------------------------------
+// k_quantize: one block = one 16 x 64 output tile, 4 pixels per lane in every
+// phase, planar (per-channel) LDS images read and written as dwords.
+//   A  source tile (halo 5, origin C0-8 so that columns are dword aligned) ->
+//      LDS, channels de-interleaved with v_perm; border tiles take the clamped
+//      (BORDER_REPLICATE) byte path.
+//   P  optional: cv::pyrDown of the tile (the next pyramid level's source
+//      image) straight from the LDS tile.
+//   B  horizontal 7-tap {8,28,56,72,56,28,8}: two v_dot4_u32_u8 per output,
+//      windows assembled with v_alignbyte; exact 8.8 fixed point (u16).
+//   C  vertical 7-tap on the u16 rows with v_dot2_u32_u16, one rounding
+//      (sum + 2^15) >> 16 -> u8 smoothed tile; border tiles then replicate the
+//      smoothed edge outwards (that is Sobel's BORDER_REPLICATE).
+//   D  Sobel 3x3 per channel, channel of maximum magnitude, fastAtan2, 16 -> 8
+//      orientation bins, 'strong' flag (mag > weak^2).
+//   E  3x3 majority vote (>= 5 of 9) around strong pixels -> one-hot byte.
+// ---------------------------------------------------------------------------
+constexpr int QS_W = 80; // source tile width  (cols C0-8 .. C0+71)
+constexpr int QH_W = 72; // h / smoothed / q tile width (cols C0-4 .. C0+67)
+
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b), c, false);
+}
+
+template <int CH, bool WITH_FLOAT>
 __global__ __launch_bounds__(256) void k_quantize(const uint8_t* __restrict__ img, int rows, int cols,
                                                   int stride, const uint8_t* __restrict__ mask,
                                                   float thr_sq, uint8_t* __restrict__ out,
-                                                  float* __restrict__ mag_out, float* __restrict__ ori_out)
+                                                  float* __restrict__ mag_out, float* __restrict__ ori_out,
+                                                  uint8_t* __restrict__ pyr_out)
 {
-    __shared__ uint8_t s_src[QS_R][QS_C * CH];
-    __shared__ uint16_t s_h[QS_R][QM_C * CH];
-    __shared__ uint8_t s_sm[QM_R][QM_C * CH];
-    __shared__ uint8_t s_q[QQ_R][QQ_C];
+    __shared__ uint32_t s_src[CH][QS_R][QS_W / 4]; // u8 x4
+    __shared__ uint32_t s_h[CH][QS_R][QH_W / 2];   // u16 x2
+    __shared__ uint32_t s_sm[CH][QM_R][QH_W / 4];  // u8 x4
+    __shared__ uint32_t s_q[QQ_R][QH_W / 4];       // u8 x4: bin | strong << 3
     const int tid = threadIdx.x;
     const int R0 = blockIdx.y * QT_R, C0 = blockIdx.x * QT_C;
-    const int K[7] = {8, 28, 56, 72, 56, 28, 8};
+    const bool interior = R0 >= 5 && R0 + QT_R + 5 <= rows && C0 >= 8 && C0 + QT_C + 8 <= cols;
 
-    // A: source tile, BORDER_REPLICATE by clamping the coordinates
-    for (int idx = tid; idx < QS_R * QS_C * CH; idx += 256) {
-        int r = idx / (QS_C * CH), rem = idx - r * (QS_C * CH);
-        int c = rem / CH, k = rem - c * CH;
-        int gr = clampi(R0 - 5 + r, 0, rows - 1), gc = clampi(C0 - 5 + c, 0, cols - 1);
-        s_src[r][rem] = img[(size_t)gr * stride + gc * CH + k];
-    }
-    __syncthreads();
-    // B: horizontal 7-tap, exact 8.8 fixed point, evaluated AT the clamped column
-    for (int idx = tid; idx < QS_R * QM_C * CH; idx += 256) {
-        int r = idx / (QM_C * CH), rem = idx - r * (QM_C * CH);
-        int j = rem / CH, k = rem - j * CH;
-        int cc = clampi(C0 - 2 + j, 0, cols - 1);
-        int base = cc - C0 + 2;
-        int acc = 0;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) acc += K[i] * s_src[r][(base + i) * CH + k];
-        s_h[r][rem] = (uint16_t)acc;
-    }
-    __syncthreads();
-    // C: vertical 7-tap, one rounding: (sum + 2^15) >> 16
-    for (int idx = tid; idx < QM_R * QM_C * CH; idx += 256) {
-        int jr = idx / (QM_C * CH), x = idx - jr * (QM_C * CH);
-        int rr = clampi(R0 - 2 + jr, 0, rows - 1);
-        int rb = rr - R0 + 2;
-        uint32_t acc = 0;
-#pragma unroll
-        for (int j = 0; j < 7; ++j) acc += (uint32_t)K[j] * s_h[rb + j][x];
-        s_sm[jr][x] = (uint8_t)((acc + 32768u) >> 16);
-    }
-    __syncthreads();
-    // D: Sobel 3x3 on the (replicate-clamped) smoothed tile, magnitude, phase, 16->8 bins
-    for (int idx = tid; idx < QQ_R * QQ_C; idx += 256) {
-        int qr = idx / QQ_C, qc = idx - qr * QQ_C;
-        int r = R0 - 1 + qr, c = C0 - 1 + qc;
-        uint8_t code = 0;
-        if (r >= 0 && r < rows && c >= 0 && c < cols) {
-            const int jr = qr + 1, jc = qc + 1;
-            int bx = 0, by = 0, bm = -1;
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                int a00 = s_sm[jr - 1][(jc - 1) * CH + k], a01 = s_sm[jr - 1][jc * CH + k], a02 = s_sm[jr - 1][(jc + 1) * CH + k];
-                int a10 = s_sm[jr][(jc - 1) * CH + k], a12 = s_sm[jr][(jc + 1) * CH + k];
-                int a20 = s_sm[jr + 1][(jc - 1) * CH + k], a21 = s_sm[jr + 1][jc * CH + k], a22 = s_sm[jr + 1][(jc + 1) * CH + k];
-                int gx = (a02 - a00) + 2 * (a12 - a10) + (a22 - a20);
-                int gy = (a20 - a00) + 2 * (a21 - a01) + (a22 - a02);
-                int m = gx * gx + gy * gy;
-                // channel of maximum magnitude, ties to the lower channel index (:370-387)
-                if (m > bm) {
-                    bm = m;
-                    bx = gx;
-                    by = gy;
-                }
-            }
-            float fx = (float)bx, fy = (float)by;
-            float mag = (float)bm;
-            float ang = fast_atan2_deg(fy, fx);
-            int q16 = __float2int_rn(__fmul_rn(ang, (float)(16.0 / 360.0)));
-            q16 = q16 < 0 ? 0 : (q16 > 255 ? 255 : q16);
-            bool ring = (r == 0) || (r == rows - 1) || (c == 0) || (c == cols - 1);
-            int q = ring ? 0 : (q16 & 7);
-            code = (uint8_t)(q | ((mag > thr_sq) ? 8 : 0));
-            if (qr >= 1 && qr <= QT_R && qc >= 1 && qc <= QT_C) {
-                if (mag_out) mag_out[(size_t)r * cols + c] = mag;
-                if (ori_out) ori_out[(size_t)r * cols + c] = ang;
+    // ---- A: source tile -> planar LDS ----
+    if (interior) {
+        for (int it = tid; it < QS_R * (QS_W / 4); it += 256) {
+            const int r = it / (QS_W / 4), g = it - r * (QS_W / 4);
+            const uint8_t* p = img + (size_t)(R0 - 5 + r) * stride + (size_t)(C0 - 8 + 4 * g) * CH;
+            if (CH == 1) {
+                s_src[0][r][g] = ld_u32_any(p);
+            } else {
+                const uint32_t d0 = ld_u32_any(p), d1 = ld_u32_any(p + 4), d2 = ld_u32_any(p + 8);
+                // 12 interleaved bytes b0..b11 -> channel k = {b[k], b[k+3], b[k+6], b[k+9]}
+                s_src[0][r][g] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c060300u), 0x05020100u);
+                s_src[1 % CH][r][g] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c070401u), 0x06020100u);
+                s_src[2 % CH][r][g] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c0c0502u), 0x07040100u);
             }
         }
-        s_q[qr][qc] = code;
+    } else {
+        uint8_t* sb = (uint8_t*)&s_src[0][0][0];
+        for (int it = tid; it < CH * QS_R * QS_W; it += 256) {
+            const int k = it / (QS_R * QS_W), rem = it - k * (QS_R * QS_W);
+            const int r = rem / QS_W, c = rem - r * QS_W;
+            const int gr = clampi(R0 - 5 + r, 0, rows - 1), gc = clampi(C0 - 8 + c, 0, cols - 1);
+            sb[it] = img[(size_t)gr * stride + gc * CH + k];
+        }
     }
     __syncthreads();
-    // E: 3x3 majority vote (>= 5 of 9), one-hot byte; 4 pixels per lane
+
+    // ---- P: pyrDown of this tile (8 x 32 outputs), REFLECT_101 at the image border ----
+    if (pyr_out) {
+        const int yy = tid >> 5, xx = tid & 31;
+        const int oy = (R0 >> 1) + yy, ox = (C0 >> 1) + xx;
+        const int drows = rows >> 1, dcols = cols >> 1;
+        if (oy < drows && ox < dcols) {
+            int ri[5], ci[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                ri[j] = reflect101(2 * oy + j - 2, rows) - (R0 - 5);
+                ci[j] = reflect101(2 * ox + j - 2, cols) - (C0 - 8);
+            }
+            const int K5[5] = {1, 4, 6, 4, 1};
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const uint8_t* sb = (const uint8_t*)&s_src[k][0][0];
+                int acc = 0;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    int h = 0;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) h += K5[i] * sb[ri[j] * QS_W + ci[i]];
+                    acc += K5[j] * h;
+                }
+                pyr_out[((size_t)oy * dcols + ox) * CH + k] = (uint8_t)((acc + 128) >> 8);
+            }
+        }
+    }
+
+    // ---- B: horizontal 7-tap: output x (image col C0-4+x) reads source bytes x+1 .. x+7 ----
+    for (int it = tid; it < CH * QS_R * (QH_W / 4); it += 256) {
+        const int k = it / (QS_R * (QH_W / 4)), rem = it - k * (QS_R * (QH_W / 4));
+        const int r = rem / (QH_W / 4), g = rem - r * (QH_W / 4);
+        const uint32_t d0 = s_src[k][r][g], d1 = s_src[k][r][g + 1], d2 = s_src[k][r][g + 2];
+        const uint32_t KLO = 0x48381C08u; // 8, 28, 56, 72
+        const uint32_t KHI = 0x00081C38u; // 56, 28, 8, 0
+        uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KLO, 0u, false);
+        h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KHI, h0, false);
+        uint32_t h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KLO, 0u, false);
+        h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KHI, h1, false);
+        uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KLO, 0u, false);
+        h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KHI, h2, false);
+        uint32_t h3 = __builtin_amdgcn_udot4(d1, KLO, 0u, false);
+        h3 = __builtin_amdgcn_udot4(d2, KHI, h3, false);
+        s_h[k][r][2 * g] = h0 | (h1 << 16);
+        s_h[k][r][2 * g + 1] = h2 | (h3 << 16);
+    }
+    __syncthreads();
+
+    // ---- C: vertical 7-tap over s_h rows jr .. jr+6, two pixels (one dword column) per item ----
+    for (int it = tid; it < CH * QM_R * (QH_W / 2); it += 256) {
+        const int k = it / (QM_R * (QH_W / 2)), rem = it - k * (QM_R * (QH_W / 2));
+        const int jr = rem / (QH_W / 2), d = rem - jr * (QH_W / 2);
+        uint32_t a[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) a[j] = s_h[k][jr + j][d];
+        const uint32_t K01 = 8u | (28u << 16), K23 = 56u | (72u << 16), K45 = 56u | (28u << 16);
+        // (row j, row j+1) pairs of the same pixel: low halves / high halves
+        uint32_t lo = udot2(__builtin_amdgcn_perm(a[1], a[0], 0x05040100u), K01, 32768u);
+        uint32_t hi = udot2(__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), K01, 32768u);
+        lo = udot2(__builtin_amdgcn_perm(a[3], a[2], 0x05040100u), K23, lo);
+        hi = udot2(__builtin_amdgcn_perm(a[3], a[2], 0x07060302u), K23, hi);
+        lo = udot2(__builtin_amdgcn_perm(a[5], a[4], 0x05040100u), K45, lo);
+        hi = udot2(__builtin_amdgcn_perm(a[5], a[4], 0x07060302u), K45, hi);
+        lo += 8u * (a[6] & 0xffffu);
+        hi += 8u * (a[6] >> 16);
+        ((uint16_t*)&s_sm[k][jr][0])[d] = (uint16_t)((lo >> 16) | ((hi >> 16) << 8));
+    }
+    __syncthreads();
+    if (!interior) { // replicate the smoothed image outwards: Sobel runs with BORDER_REPLICATE
+        uint8_t* sm = (uint8_t*)&s_sm[0][0][0];
+        for (int it = tid; it < CH * QM_R * QH_W; it += 256) {
+            const int k = it / (QM_R * QH_W), rem = it - k * (QM_R * QH_W);
+            const int jr = rem / QH_W, x = rem - jr * QH_W;
+            const int r = R0 - 2 + jr, c = C0 - 4 + x;
+            if (r < 0 || r >= rows || c < 0 || c >= cols) {
+                const int rr = clampi(r, 0, rows - 1) - (R0 - 2), cc = clampi(c, 0, cols - 1) - (C0 - 4);
+                if (rr >= 0 && rr < QM_R && cc >= 0 && cc < QH_W) sm[(k * QM_R + jr) * QH_W + x] = sm[(k * QM_R + rr) * QH_W + cc];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- D: Sobel + magnitude + orientation bin; q row qr <-> image row R0-1+qr <-> s_sm row qr+1 ----
+    for (int it = tid; it < QQ_R * (QH_W / 4); it += 256) {
+        const int qr = it / (QH_W / 4), g = it - qr * (QH_W / 4);
+        const int gm = g > 0 ? g - 1 : 0, gp = g < QH_W / 4 - 1 ? g + 1 : g;
+        int bx[4] = {0, 0, 0, 0}, by[4] = {0, 0, 0, 0}, bm[4] = {-1, -1, -1, -1};
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            int p[3][6]; // rows jr-1, jr, jr+1; columns x-1 .. x+4
+#pragma unroll
+            for (int rw = 0; rw < 3; ++rw) {
+                const uint32_t dl = s_sm[k][qr + rw][gm], dc = s_sm[k][qr + rw][g], dr = s_sm[k][qr + rw][gp];
+                p[rw][0] = (int)(dl >> 24);
+                p[rw][1] = (int)(dc & 0xff);
+                p[rw][2] = (int)((dc >> 8) & 0xff);
+                p[rw][3] = (int)((dc >> 16) & 0xff);
+                p[rw][4] = (int)(dc >> 24);
+                p[rw][5] = (int)(dr & 0xff);
+            }
+            int cw[6], dd[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                cw[c] = p[0][c] + 2 * p[1][c] + p[2][c];
+                dd[c] = p[2][c] - p[0][c];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int gx = cw[m + 2] - cw[m];
+                const int gy = dd[m] + 2 * dd[m + 1] + dd[m + 2];
+                const int mg = gx * gx + gy * gy;
+                if (mg > bm[m]) { // maximum magnitude, ties to the lower channel (:370-387)
+                    bm[m] = mg;
+                    bx[m] = gx;
+                    by[m] = gy;
+                }
+            }
+        }
+        uint32_t codes = 0;
+        const int r = R0 - 1 + qr;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int c = C0 - 4 + 4 * g + m;
+            uint32_t code = 0;
+            if (r >= 0 && r < rows && c >= 0 && c < cols) {
+                const float mag = (float)bm[m];
+                const float ang = fast_atan2_deg((float)by[m], (float)bx[m]);
+                int q16 = __float2int_rn(__fmul_rn(ang, (float)(16.0 / 360.0)));
+                q16 = q16 < 0 ? 0 : (q16 > 255 ? 255 : q16);
+                const bool ring = (r == 0) || (r == rows - 1) || (c == 0) || (c == cols - 1);
+                code = (uint32_t)(ring ? 0 : (q16 & 7)) | ((mag > thr_sq) ? 8u : 0u);
+                if (WITH_FLOAT) {
+                    if (qr >= 1 && qr <= QT_R && c >= C0 && c < C0 + QT_C) {
+                        if (mag_out) mag_out[(size_t)r * cols + c] = mag;
+                        if (ori_out) ori_out[(size_t)r * cols + c] = ang;
+                    }
+                }
+            }
+            codes |= code << (8 * m);
+        }
+        s_q[qr][g] = codes;
+    }
+    __syncthreads();
+
+    // ---- E: 3x3 majority vote (>= 5 of 9); out cols C0+4g .. +3 <-> q columns 4(g+1) .. +3 ----
     {
-        const int er = tid >> 4, c4 = (tid & 15) * 4;
+        const int er = tid >> 4, g = tid & 15;
         const int r = R0 + er;
         if (r < rows) {
-            uint32_t packed = 0;
+            uint32_t nb[3][3];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = C0 + c4 + k;
-                uint32_t v = 0;
-                if (c < cols && r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1) {
-                    const int qr = er + 1, qc = c4 + k + 1;
-                    if (s_q[qr][qc] & 8) {
-                        uint32_t h = 0; // eight 4-bit vote counters
-#pragma unroll
-                        for (int dr = -1; dr <= 1; ++dr)
-#pragma unroll
-                            for (int dc = -1; dc <= 1; ++dc) h += 1u << (4 * (s_q[qr + dr][qc + dc] & 7));
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            if (((h >> (4 * i)) & 15u) >= 5u) v = 1u << i;
-                    }
-                    if (mask && !mask[(size_t)r * cols + c]) v = 0;
-                }
-                packed |= v << (8 * k);
+            for (int rw = 0; rw < 3; ++rw) {
+                nb[rw][0] = s_q[er + rw][g];
+                nb[rw][1] = s_q[er + rw][g + 1];
+                nb[rw][2] = s_q[er + rw][g + 2];
             }
-            uint8_t* o = out + (size_t)r * cols + C0 + c4;
-            if (C0 + c4 + 3 < cols && ((((size_t)r * cols + C0 + c4) & 3) == 0)) {
+            const uint32_t centre = nb[1][1];
+            uint32_t packed = 0;
+            if (centre & 0x08080808u) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int c = C0 + 4 * g + m;
+                    if (!((centre >> (8 * m)) & 8u)) continue;
+                    if (!(c < cols && r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1)) continue;
+                    uint32_t h = 0; // eight 4-bit vote counters
+#pragma unroll
+                    for (int rw = 0; rw < 3; ++rw) {
+                        // columns m-1, m, m+1 relative to the centre dword
+                        const uint32_t left = m == 0 ? (nb[rw][0] >> 24) : (nb[rw][1] >> (8 * (m - 1)));
+                        const uint32_t mid = nb[rw][1] >> (8 * m);
+                        const uint32_t right = m == 3 ? nb[rw][2] : (nb[rw][1] >> (8 * (m + 1)));
+                        h += 1u << (4 * (left & 7));
+                        h += 1u << (4 * (mid & 7));
+                        h += 1u << (4 * (right & 7));
+                    }
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (((h >> (4 * i)) & 15u) >= 5u) v = 1u << i;
+                    if (mask && !mask[(size_t)r * cols + c]) v = 0;
+                    packed |= v << (8 * m);
+                }
+            }
+            uint8_t* o = out + (size_t)r * cols + C0 + 4 * g;
+            if (C0 + 4 * g + 3 < cols && ((((size_t)r * cols + C0 + 4 * g) & 3) == 0)) {
                 *(uint32_t*)o = packed;
             } else {
-                for (int k = 0; k < 4; ++k)
-                    if (C0 + c4 + k < cols) o[k] = (uint8_t)(packed >> (8 * k));
+                for (int m = 0; m < 4; ++m)
+                    if (C0 + 4 * g + m < cols) o[m] = (uint8_t)(packed >> (8 * m));
             }
         }
     }
 }
 
-// cv::pyrDown: [1 4 6 4 1]^2, (sum + 128) >> 8, REFLECT_101; dst = (rows/2, cols/2)
+// cv::pyrDown: [1 4 6 4 1]^2, (sum + 128) >> 8, REFLECT_101; dst = (rows/2, cols/2).
+// One lane per output pixel (all channels).  Interior pixels of 1- and 3-channel
+// images read each of the 5 source rows as unaligned dwords; the border ring
+// takes the reflect path.
 __global__ __launch_bounds__(256) void k_pyrdown(const uint8_t* __restrict__ src, int rows, int cols, int ch,
                                                  int stride, uint8_t* __restrict__ dst)
 {
     const int dr = rows / 2, dc = cols / 2;
-    const int n = dr * dc * ch;
+    const int n = dr * dc;
     const int K[5] = {1, 4, 6, 4, 1};
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
-        int k = idx % ch, x = (idx / ch) % dc, y = idx / (ch * dc);
-        int acc = 0;
+        const int x = idx % dc, y = idx / dc;
+        const bool interior = x >= 1 && y >= 1 && 2 * x + 2 < cols && 2 * y + 2 < rows &&
+                              (2 * x - 2) * ch + 16 <= stride; // the 16-byte row read stays inside the row
+        if (interior && ch == 3) {
+            int acc[3] = {0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const uint8_t* s = src + (size_t)reflect101(2 * y + j - 2, rows) * stride;
-            int h = 0;
+            for (int j = 0; j < 5; ++j) {
+                const uint8_t* s = src + (size_t)(2 * y + j - 2) * stride + (2 * x - 2) * 3;
+                uint32_t w[4];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) h += K[i] * s[reflect101(2 * x + i - 2, cols) * ch + k];
-            acc += K[j] * h;
+                for (int q = 0; q < 4; ++q) w[q] = ld_u32_any(s + 4 * q);
+                int h[3] = {0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int b = i * 3 + k;
+                        h[k] += K[i] * (int)((w[b >> 2] >> (8 * (b & 3))) & 0xff);
+                    }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc[k] += K[j] * h[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dst[(size_t)idx * 3 + k] = (uint8_t)((acc[k] + 128) >> 8);
+        } else if (interior && ch == 1) {
+            int acc = 0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const uint8_t* s = src + (size_t)(2 * y + j - 2) * stride + (2 * x - 2);
+                uint32_t w0 = ld_u32_any(s);
+                int h = (int)(w0 & 0xff) + 4 * (int)((w0 >> 8) & 0xff) + 6 * (int)((w0 >> 16) & 0xff) + 4 * (int)(w0 >> 24) + (int)s[4];
+                acc += K[j] * h;
+            }
+            dst[idx] = (uint8_t)((acc + 128) >> 8);
+        } else {
+            for (int k = 0; k < ch; ++k) {
+                int acc = 0;
+                for (int j = 0; j < 5; ++j) {
+                    const uint8_t* s = src + (size_t)reflect101(2 * y + j - 2, rows) * stride;
+                    int h = 0;
+                    for (int i = 0; i < 5; ++i) h += K[i] * s[reflect101(2 * x + i - 2, cols) * ch + k];
+                    acc += K[j] * h;
+                }
+                dst[(size_t)idx * ch + k] = (uint8_t)((acc + 128) >> 8);
+            }
         }
-        dst[idx] = (uint8_t)((acc + 128) >> 8);
     }
 }
 
@@ -314,6 +491,88 @@ __global__ __launch_bounds__(256) void k_build_lm(const uint8_t* __restrict__ q,
     }
 }
 
+// ---- register-only variant for T = 4 and T = 8 (the reference's strides) ----
+// One lane owns 4 consecutive grid cells (4*T pixels) of one (ty, gy) pixel row
+// r0 = gy*T + ty: it ORs the T source rows r0..r0+T-1 (16-byte loads), ORs T
+// pixels forward with funnel shifts, transposes the 4 cells x T sub-columns in
+// registers (v_perm), and for every tx and orientation stores one dword =
+// responses of cells gx..gx+3.  A wave's store is one contiguous run of
+// LM[o][ty*T+tx][gy*W + ...]: no LDS, no barrier, fully coalesced.
+// Requires W % 4 == 0 and cols % 16 == 0 (host checks; else k_build_lm).
+__device__ __forceinline__ uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    return __builtin_amdgcn_perm(hi, lo, sel);
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void k_build_lm_rows(const uint8_t* __restrict__ q, int rows, int cols, int W,
+                                                       int H, uint8_t* __restrict__ lm, int64_t lm_stride)
+{
+    constexpr int NQ = T / 4 * 4; // dwords of own pixels per lane (4 cells * T px / 4)
+    const int lanes_per_row = W >> 2;
+    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row_id = item / lanes_per_row; // = gy * T + ty  (a pixel row index)
+    const int k = (int)(item - row_id * lanes_per_row);
+    if (row_id >= rows) return;
+    const int r0 = (int)row_id;
+    const int gy = r0 / T, ty = r0 - gy * T;
+    const int c0 = k * 4 * T; // first pixel column of this lane
+    // vertical OR of rows r0 .. r0+T-1 (clipped at the bottom, :626-627), own pixels + T px of right halo
+    uint32_t v[NQ + T / 4];
+#pragma unroll
+    for (int i = 0; i < NQ + T / 4; ++i) v[i] = 0;
+#pragma unroll
+    for (int d = 0; d < T; ++d) {
+        const int r = r0 + d;
+        if (r < rows) {
+            const uint8_t* src = q + (size_t)r * cols + c0;
+#pragma unroll
+            for (int i = 0; i < NQ; i += 4) {
+                const uint4 w = *(const uint4*)(src + 4 * i);
+                v[i] |= w.x;
+                v[i + 1] |= w.y;
+                v[i + 2] |= w.z;
+                v[i + 3] |= w.w;
+            }
+            if (c0 + 4 * NQ < cols) { // right halo (zero past the last column)
+#pragma unroll
+                for (int i = 0; i < T / 4; ++i) v[NQ + i] |= *(const uint32_t*)(src + 4 * (NQ + i));
+            }
+        }
+    }
+    // horizontal OR over T pixels forward: byte c |= bytes c+1 .. c+T-1
+    uint32_t s[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        uint32_t a = v[i], b = v[i + 1];
+        uint32_t o = a | __builtin_amdgcn_alignbyte(b, a, 1) | __builtin_amdgcn_alignbyte(b, a, 2) |
+                     __builtin_amdgcn_alignbyte(b, a, 3);
+        if (T == 8) {
+            uint32_t c2 = v[i + 2];
+            o |= b | __builtin_amdgcn_alignbyte(c2, b, 1) | __builtin_amdgcn_alignbyte(c2, b, 2) |
+                 __builtin_amdgcn_alignbyte(c2, b, 3);
+        }
+        s[i] = o;
+    }
+    // s[] holds 4 cells x T sub-columns; gather, per tx, the 4 cells' bytes into one dword
+    const int64_t WH = (int64_t)W * H;
+    const int64_t cell = (int64_t)gy * W + k * 4;
+#pragma unroll
+    for (int tx = 0; tx < T; ++tx) {
+        // cell j lives in dwords s[j*T/4 .. ], sub-column tx is byte (tx & 3) of dword j*(T/4) + (tx >> 2)
+        const int dsel = tx >> 2, b = tx & 3;
+        const uint32_t d0 = s[0 * (T / 4) + dsel], d1 = s[1 * (T / 4) + dsel], d2 = s[2 * (T / 4) + dsel],
+                       d3 = s[3 * (T / 4) + dsel];
+        // v_perm selector bytes: 0-3 pick from 'lo', 4-7 from 'hi'
+        const uint32_t p01 = perm_b32(d1, d0, 0x0c0c0000u | ((4 + b) << 8) | b);        // {d0.b, d1.b, 0, 0}
+        const uint32_t p23 = perm_b32(d3, d2, 0x00000c0cu | ((4 + b) << 24) | (b << 16)); // {0, 0, d2.b, d3.b}
+        const uint32_t sp = p01 | p23;
+        const int64_t dst = (int64_t)(ty * T + tx) * WH + cell;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) *(uint32_t*)(lm + o * lm_stride + dst) = response4(sp, o);
+    }
+}
+
 // unfused single-function kernels (stage entry points / parity tests)
 __global__ __launch_bounds__(256) void k_spread(const uint8_t* __restrict__ src, int rows, int cols, int T,
                                                 uint8_t* __restrict__ dst)
@@ -383,37 +642,145 @@ __device__ __forceinline__ int template_positions(const DevTL& tl, int W, int H,
 }
 
 constexpr int SIM_POS_PER_BLOCK = 1024; // 256 lanes x 4 positions
+constexpr int FB = 8;                   // features per batch: FB independent loads in flight per lane
 
-// Accumulate 4 consecutive positions per lane.  Packed-u8 adds are carry-free
-// for up to 63 features (63 * 4 = 252); flushed into two packed-u16 words.
-__device__ __forceinline__ void coarse_accumulate(const uint8_t* __restrict__ lm, const DevTL tl,
-                                                  const uint32_t* __restrict__ fxy,
-                                                  const int32_t* __restrict__ foff, int rows, int cols,
-                                                  int j0, uint32_t& lo, uint32_t& hi)
+// Sum `count` features starting at `f0` into packed 16-bit lanes.  Each lane
+// owns 4 consecutive bytes at lm + foff[f] + lane_off.  The wave first loads 64
+// features' (position, offset) records with one vector load per array, then
+// broadcasts them one at a time with v_readlane: the inner loop is branch-free
+// and keeps FB independent 4-byte loads in flight per lane.  MUST be called with
+// all 64 lanes of the wave active (v_readlane reads lanes regardless of EXEC, and
+// an inactive lane's record would be stale).  A feature that is
+// out of the image (skipped by the reference, :836-837 / :878-879) or past the
+// end of the range reads zero bytes from the linear memories' zero tail.
+// Packed-u8 partial sums are carry-free for <= 63 addends (63 * 4 = 252) and
+// are flushed into two packed-u16 words before that.
+__device__ __forceinline__ void accumulate_features(const uint8_t* __restrict__ lm,
+                                                    const uint32_t* __restrict__ fxy,
+                                                    const int32_t* __restrict__ foff, int f0, int count,
+                                                    int rows, int cols, int ox, int oy, int lane_off,
+                                                    const uint8_t* __restrict__ zero_addr, int zero_lane_off,
+                                                    uint32_t& lo, uint32_t& hi)
 {
+    const int lane = threadIdx.x & 63;
+    const uint8_t* p_ok = lm + lane_off;
+    const uint8_t* p_zero = zero_addr + zero_lane_off;
     uint32_t acc = 0;
     lo = hi = 0;
     int pending = 0;
-    for (int f = 0; f < tl.nf; ++f) {
-        const uint32_t xy = fxy[tl.feat_off + f];
-        const int x = xy & 0xffff, y = xy >> 16;
-        if (x >= cols || y >= rows) continue; // out-of-image features are skipped (:836-837)
-        acc += ld_u32_any(lm + foff[tl.feat_off + f] + j0);
-        if (++pending == 63) {
-            lo += acc & 0x00ff00ffu;
-            hi += (acc >> 8) & 0x00ff00ffu;
-            acc = 0;
-            pending = 0;
+    for (int b = 0; b < count; b += 64) {
+        int sel = -1;
+        if (b + lane < count) {
+            const uint32_t xy = fxy[f0 + b + lane];
+            const int x = (int)(xy & 0xffff) + ox, y = (int)(xy >> 16) + oy;
+            if (x >= 0 && y >= 0 && x < cols && y < rows) sel = foff[f0 + b + lane];
+        }
+        const int nb = count - b < 64 ? count - b : 64;
+        for (int u = 0; u < nb; u += FB) {
+            uint32_t v[FB];
+#pragma unroll
+            for (int k = 0; k < FB; ++k) {
+                const int o = __builtin_amdgcn_readlane(sel, (u + k) & 63);
+                v[k] = ld_u32_any(o >= 0 ? p_ok + o : p_zero);
+            }
+#pragma unroll
+            for (int k = 0; k < FB; ++k) acc += v[k];
+            pending += FB;
+            if (pending + FB > 63) {
+                lo += acc & 0x00ff00ffu;
+                hi += (acc >> 8) & 0x00ff00ffu;
+                acc = 0;
+                pending = 0;
+            }
         }
     }
     lo += acc & 0x00ff00ffu;
     hi += (acc >> 8) & 0x00ff00ffu;
 }
 
-// grid = (position chunks, active templates).  Fused threshold scan: no score
-// map is written; candidates are appended with one atomic per wave.
-__global__ __launch_bounds__(256) void k_similarity_coarse(
-    const uint8_t* __restrict__ lm, int rows, int cols, int T, int W, int H, int L, int lc,
+__device__ __forceinline__ int unpack4(uint32_t lo, uint32_t hi, int k)
+{
+    return (k & 1) ? (int)((hi >> (8 * (k - 1))) & 0xffff) : (int)((lo >> (8 * k)) & 0xffff);
+}
+
+// 16 consecutive positions per lane: one 4-byte-aligned 16-byte load plus one
+// 4-byte load per feature, re-aligned with v_alignbyte by the (wave-uniform)
+// byte misalignment of the feature's linear-memory offset.  Measured on
+// MI355X (tools/ld_probe.hip): 4-byte-aligned dwordx4 streams from L2 at
+// ~12 TB/s, twice the rate of dword loads and of byte-misaligned dwordx4.
+// j0 must be a multiple of 4.  Same calling convention as accumulate_features
+// (all 64 lanes active).  lo[i]/hi[i]: packed u16 sums of bytes 4i..4i+3.
+__device__ __forceinline__ void accumulate_features16(const uint8_t* __restrict__ lm,
+                                                      const uint32_t* __restrict__ fxy,
+                                                      const int32_t* __restrict__ foff, int count,
+                                                      int rows, int cols, int j0, int zero_off,
+                                                      uint32_t (&lo)[4], uint32_t (&hi)[4])
+{
+    const int lane = threadIdx.x & 63;
+    const uint8_t* p = lm + j0;
+    uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lo[i] = hi[i] = 0;
+    int pending = 0;
+    for (int b = 0; b < count; b += 64) {
+        int sel = zero_off;
+        if (b + lane < count) {
+            const uint32_t xy = fxy[b + lane];
+            const int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
+            if (x < cols && y < rows) sel = foff[b + lane];
+        }
+        const int nb = count - b < 64 ? count - b : 64;
+        for (int u = 0; u < nb; u += FB) {
+            u128_a4 q[FB];
+            uint32_t e[FB];
+            int sh[FB];
+#pragma unroll
+            for (int k = 0; k < FB; ++k) {
+                const int o = (u + k < nb) ? __builtin_amdgcn_readlane(sel, (u + k) & 63) : zero_off;
+                sh[k] = o & 3;
+                const uint8_t* a = p + (o & ~3);
+                q[k] = *(const u128_a4*)a;
+                e[k] = *(const uint32_t*)(a + 16);
+            }
+#pragma unroll
+            for (int k = 0; k < FB; ++k) {
+                acc[0] += __builtin_amdgcn_alignbyte(q[k].y, q[k].x, sh[k]);
+                acc[1] += __builtin_amdgcn_alignbyte(q[k].z, q[k].y, sh[k]);
+                acc[2] += __builtin_amdgcn_alignbyte(q[k].w, q[k].z, sh[k]);
+                acc[3] += __builtin_amdgcn_alignbyte(e[k], q[k].w, sh[k]);
+            }
+            pending += FB;
+            if (pending + FB > 63) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lo[i] += acc[i] & 0x00ff00ffu;
+                    hi[i] += (acc[i] >> 8) & 0x00ff00ffu;
+                    acc[i] = 0;
+                }
+                pending = 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lo[i] += acc[i] & 0x00ff00ffu;
+        hi[i] += (acc[i] >> 8) & 0x00ff00ffu;
+    }
+}
+
+// zero the per-call counters (one launch instead of two memsets)
+__global__ void k_reset(int32_t* __restrict__ counters, int32_t* __restrict__ out_count)
+{
+    if (threadIdx.x < 4) counters[threadIdx.x] = 0;
+    if (threadIdx.x < 2) out_count[threadIdx.x] = 0;
+}
+
+// grid = (position chunks of 1024, active templates), one wave per block, 16
+// positions per lane.  Fused threshold scan: no score map is written;
+// candidates are appended with an atomic counter.
+constexpr int COARSE_POS_PER_BLOCK = 1024;
+__global__ __launch_bounds__(64) void k_similarity_coarse(
+    const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int lc,
     const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
     const int32_t* __restrict__ active, const int32_t* __restrict__ raw_min, Cand* __restrict__ cands,
     int32_t* __restrict__ counters, int cap)
@@ -422,27 +789,42 @@ __global__ __launch_bounds__(256) void k_similarity_coarse(
     const DevTL tl = tls[(size_t)t * L + lc];
     const int npos = template_positions(tl, W, H, T);
     const int rmin = raw_min[(size_t)t * L + lc];
-    const int base = blockIdx.x * SIM_POS_PER_BLOCK;
+    const int base = blockIdx.x * COARSE_POS_PER_BLOCK;
     const int total = W * H;
     if (base >= total) return;
     if (base >= npos && rmin > 0) return; // beyond the span every score is 0
-    const int j0 = base + threadIdx.x * 4;
-    uint32_t lo = 0, hi = 0;
-    if (j0 < npos) coarse_accumulate(lm, tl, fxy, foff, rows, cols, j0, lo, hi);
+    const int j0 = base + threadIdx.x * 16;
+    uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+    if (base < npos) { // block-uniform: every lane takes part (features are spread over the wave's lanes)
+        const int zero_off = (int)(7 * lm_stride + (int64_t)T * T * W * H); // zero tail of the last orientation
+        const int jl = j0 < npos ? j0 : 0; // lanes past the span load valid bytes and discard them
+        accumulate_features16(lm, fxy + tl.feat_off, foff + tl.feat_off, tl.nf, rows, cols, jl, zero_off, lo, hi);
+    }
     const int offset = T / 2 + (T % 2 - 1);
+    bool any = false;
+    int raws[16];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int j = j0 + k;
-        int raw = (k & 1) ? ((hi >> (8 * (k - 1))) & 0xffff) : ((lo >> (8 * k)) & 0xffff);
-        if (j >= npos) raw = 0;
-        if (j < total && raw >= rmin) {
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + 4 * i + k;
+            int raw = unpack4(lo[i], hi[i], k);
+            if (j >= npos) raw = 0;
+            raws[4 * i + k] = raw;
+            any |= (j < total && raw >= rmin);
+        }
+    if (!any) return;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int j = j0 + m;
+        if (j < total && raws[m] >= rmin) {
             int idx = atomicAdd(&counters[0], 1);
             if (idx < cap) {
                 Cand c;
                 c.t = t;
                 c.x = (j % W) * T + offset;
                 c.y = (j / W) * T + offset;
-                c.raw = raw;
+                c.raw = raws[m];
                 cands[idx] = c;
             }
         }
@@ -450,74 +832,75 @@ __global__ __launch_bounds__(256) void k_similarity_coarse(
 }
 
 // same accumulation, score map out (stage entry point sbm_similarity)
-__global__ __launch_bounds__(256) void k_similarity_map(const uint8_t* __restrict__ lm, int rows, int cols,
-                                                        int T, int W, int H, DevTL tl,
+__global__ __launch_bounds__(256) void k_similarity_map(const uint8_t* __restrict__ lm, int64_t lm_stride,
+                                                        int rows, int cols, int T, int W, int H, DevTL tl,
                                                         const uint32_t* __restrict__ fxy,
                                                         const int32_t* __restrict__ foff,
                                                         uint16_t* __restrict__ dst)
 {
     const int npos = template_positions(tl, W, H, T);
     const int total = W * H;
-    const int j0 = blockIdx.x * SIM_POS_PER_BLOCK + threadIdx.x * 4;
-    if (j0 >= total) return;
+    const int base = blockIdx.x * SIM_POS_PER_BLOCK;
+    const int j0 = base + threadIdx.x * 4;
     uint32_t lo = 0, hi = 0;
-    if (j0 < npos) coarse_accumulate(lm, tl, fxy, foff, rows, cols, j0, lo, hi);
+    if (base < npos) { // block-uniform, all lanes take part
+        const uint8_t* zero_addr = lm + 7 * lm_stride + (int64_t)T * T * W * H;
+        const int jl = j0 < npos ? j0 : 0;
+        accumulate_features(lm, fxy + tl.feat_off, foff + tl.feat_off, 0, tl.nf, rows, cols, 0, 0, jl, zero_addr, 0, lo, hi);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int j = j0 + k;
-        int raw = (k & 1) ? ((hi >> (8 * (k - 1))) & 0xffff) : ((lo >> (8 * k)) & 0xffff);
-        if (j < total) dst[j] = (uint16_t)(j < npos ? raw : 0);
+        if (j < total) dst[j] = (uint16_t)(j < npos ? unpack4(lo, hi, k) : 0);
     }
 }
 
-// 16x16 patch of one candidate held by one wave: lane = (row = lane>>2,
-// 4 columns).  Returns packed u16 sums in lo (cols 0,2) / hi (cols 1,3).
-__device__ __forceinline__ void local_accumulate(const uint8_t* __restrict__ lm, const DevTL tl,
-                                                 const uint32_t* __restrict__ fxy,
-                                                 const int32_t* __restrict__ foff, int rows, int cols,
-                                                 int W, int T, int ox, int oy, int lane, uint32_t& lo,
-                                                 uint32_t& hi)
+// 16x16 patch of one candidate: lane = (row = lane>>2, 4 columns); the block's
+// 4 waves each take a contiguous quarter of the features and the partial sums
+// meet in LDS.  Result (packed u16) valid in wave 0.
+__device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int64_t lm_stride, const DevTL tl,
+                                            const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
+                                            int rows, int cols, int W, int H, int T, int ox, int oy,
+                                            uint32_t (*s_part)[64][2], uint32_t& lo, uint32_t& hi)
 {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane >> 2, c4 = (lane & 3) * 4;
     const int delta = (oy / T) * W + ox / T + r * W + c4;
-    uint32_t acc = 0;
-    lo = hi = 0;
-    int pending = 0;
-    for (int f = 0; f < tl.nf; ++f) {
-        const uint32_t xy = fxy[tl.feat_off + f];
-        const int x = (int)(xy & 0xffff) + ox, y = (int)(xy >> 16) + oy;
-        if (x < 0 || y < 0 || x >= cols || y >= rows) continue; // :878-879
-        acc += ld_u32_any(lm + foff[tl.feat_off + f] + delta);
-        if (++pending == 63) {
-            lo += acc & 0x00ff00ffu;
-            hi += (acc >> 8) & 0x00ff00ffu;
-            acc = 0;
-            pending = 0;
-        }
+    const uint8_t* zero_addr = lm + 7 * lm_stride + (int64_t)T * T * W * H;
+    const int chunk = (tl.nf + 3) >> 2;
+    const int f0 = wave * chunk;
+    int cnt = tl.nf - f0;
+    cnt = cnt < 0 ? 0 : (cnt > chunk ? chunk : cnt);
+    accumulate_features(lm, fxy + tl.feat_off, foff + tl.feat_off, f0, cnt, rows, cols, ox, oy, delta, zero_addr, 0, lo, hi);
+    s_part[wave][lane][0] = lo;
+    s_part[wave][lane][1] = hi;
+    __syncthreads();
+    if (wave == 0) {
+        lo = s_part[0][lane][0] + s_part[1][lane][0] + s_part[2][lane][0] + s_part[3][lane][0];
+        hi = s_part[0][lane][1] + s_part[1][lane][1] + s_part[2][lane][1] + s_part[3][lane][1];
     }
-    lo += acc & 0x00ff00ffu;
-    hi += (acc >> 8) & 0x00ff00ffu;
+    __syncthreads();
 }
 
-// One wave per candidate: refine at level l (line2Dup.cpp:1233-1287), apply the
-// per-level filter (:1290-1292); at level 0 emit the final Match record.
+// One block (4 waves) per candidate: refine at level l (line2Dup.cpp:1233-1287),
+// apply the per-level filter (:1290-1292); at level 0 emit the final Match record.
 __global__ __launch_bounds__(256) void k_similarity_local(
-    const uint8_t* __restrict__ lm, int rows, int cols, int T, int W, int L, int l,
+    const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int l,
     const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
     const int32_t* __restrict__ raw_keep, const int32_t* __restrict__ class_idx,
     const int32_t* __restrict__ template_id, Cand* __restrict__ cands, int32_t* __restrict__ counters,
     int cand_cap, int is_last, sbm_match_rec* __restrict__ out, int32_t* __restrict__ out_count,
     int out_cap)
 {
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * 4;
+    __shared__ uint32_t s_part[4][64][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int n = counters[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && is_last) out_count[1] = n > cand_cap ? 1 : 0; // overflow status
     n = n < cand_cap ? n : cand_cap;
     const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
-    for (int ci = wave; ci < n; ci += nwaves) {
+    for (int ci = blockIdx.x; ci < n; ci += gridDim.x) {
         Cand c = cands[ci];
-        if (c.raw < 0) continue; // dropped at a coarser level
+        if (c.raw < 0) continue; // dropped at a coarser level (uniform per block)
         const DevTL tl = tls[(size_t)c.t * L + l];
         int x = c.x * 2 + 1, y = c.y * 2 + 1;
         const int max_x = cols - tl.width - border, max_y = rows - tl.height - border;
@@ -527,13 +910,13 @@ __global__ __launch_bounds__(256) void k_similarity_local(
         y = y > max_y ? max_y : y;
         const int ox = (x / T - 8) * T, oy = (y / T - 8) * T;
         uint32_t lo, hi;
-        local_accumulate(lm, tl, fxy, foff, rows, cols, W, T, ox, oy, lane, lo, hi);
-        // first maximum in row-major order, strict '>' from 0 (:1265-1282):
-        // maximise (raw, -position)
+        local_patch(lm, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi);
+        if (wave != 0) continue;
+        // first maximum in row-major order, strict '>' from 0 (:1265-1282): maximise (raw, -position)
         uint32_t best = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            uint32_t raw = (k & 1) ? ((hi >> (8 * (k - 1))) & 0xffff) : ((lo >> (8 * k)) & 0xffff);
+            uint32_t raw = (uint32_t)unpack4(lo, hi, k);
             uint32_t p = (uint32_t)(lane * 4 + k);
             uint32_t key = (raw << 8) | (255u - p);
             best = key > best ? key : best;
@@ -579,20 +962,21 @@ __global__ __launch_bounds__(256) void k_similarity_local(
     }
 }
 
-// stage entry point: one 16x16 patch, one wave
-__global__ __launch_bounds__(64) void k_similarity_local_patch(const uint8_t* __restrict__ lm, int rows,
-                                                               int cols, int T, int W, DevTL tl,
-                                                               const uint32_t* __restrict__ fxy,
-                                                               const int32_t* __restrict__ foff, int cx,
-                                                               int cy, uint16_t* __restrict__ dst)
+// stage entry point: one 16x16 patch
+__global__ __launch_bounds__(256) void k_similarity_local_patch(const uint8_t* __restrict__ lm, int64_t lm_stride,
+                                                                int rows, int cols, int T, int W, int H, DevTL tl,
+                                                                const uint32_t* __restrict__ fxy,
+                                                                const int32_t* __restrict__ foff, int cx, int cy,
+                                                                uint16_t* __restrict__ dst)
 {
-    const int lane = threadIdx.x;
+    __shared__ uint32_t s_part[4][64][2];
     const int ox = (cx / T - 8) * T, oy = (cy / T - 8) * T;
     uint32_t lo, hi;
-    local_accumulate(lm, tl, fxy, foff, rows, cols, W, T, ox, oy, lane, lo, hi);
+    local_patch(lm, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi);
+    if (threadIdx.x < 64) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        dst[lane * 4 + k] = (uint16_t)((k & 1) ? ((hi >> (8 * (k - 1))) & 0xffff) : ((lo >> (8 * k)) & 0xffff));
+        for (int k = 0; k < 4; ++k) dst[threadIdx.x * 4 + k] = (uint16_t)unpack4(lo, hi, k);
+    }
 }
 
 // single-level pyramids: coarse candidates are the final matches
@@ -605,6 +989,7 @@ __global__ __launch_bounds__(256) void k_emit_coarse(const Cand* __restrict__ ca
                                                      int32_t* __restrict__ out_count, int out_cap)
 {
     int n = counters[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_count[1] = n > cand_cap ? 1 : 0;
     n = n < cand_cap ? n : cand_cap;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const Cand c = cands[i];
@@ -621,12 +1006,6 @@ __global__ __launch_bounds__(256) void k_emit_coarse(const Cand* __restrict__ ca
             out[idx] = m;
         }
     }
-}
-
-// status word: counters[1] = 1 when the candidate list overflowed
-__global__ void k_finish(int32_t* __restrict__ counters, int cand_cap, int32_t* __restrict__ out_count)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) out_count[1] = counters[0] > cand_cap ? 1 : 0;
 }
 
 } // namespace sbm
