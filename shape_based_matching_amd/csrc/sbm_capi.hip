@@ -400,7 +400,7 @@ int enqueue_templates(sbm_ctx* c, hipStream_t s, float threshold, sbm_match_rec*
         Scope sc(c, s, "k_similarity_coarse");
         for (int first = 0; first < n_active; first += 65535) {
             const int cnt = std::min(65535, n_active - first);
-            hipLaunchKernelGGL(k_similarity_coarse, dim3(chunks, cnt), dim3(64), 0, s, c->d_lm[lc].as<uint8_t>(),
+            hipLaunchKernelGGL(k_similarity_coarse, dim3(chunks, cnt), dim3(256), 0, s, c->d_lm[lc].as<uint8_t>(),
                                c->lm_stride[lc], c->rows[lc], c->cols[lc], T, W, H, L, lc, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(),
                                c->d_foff.as<int32_t>(), c->d_active.as<int32_t>() + first, c->d_rawmin.as<int32_t>(),
                                c->d_cands.as<Cand>(), counters, (int)c->cand_cap);
@@ -417,7 +417,7 @@ int enqueue_templates(sbm_ctx* c, hipStream_t s, float threshold, sbm_match_rec*
     for (int l = L - 2; l >= 0; --l) {
         const int T = c->cfg.T[l], W = c->cols[l] / T, H = c->rows[l] / T;
         Scope sc(c, s, "k_similarity_local");
-        hipLaunchKernelGGL(k_similarity_local, dim3(1024), dim3(256), 0, s, c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
+        hipLaunchKernelGGL(k_similarity_local, dim3(256), dim3(64 * LOCAL_WAVES), 0, s, c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
                            c->rows[l], c->cols[l], T, W, H, L, l, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(), c->d_foff.as<int32_t>(),
                            c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
                            c->d_cands.as<Cand>(), counters, (int)c->cand_cap, l == 0 ? 1 : 0, d_out, d_count, (int)cap);
@@ -893,7 +893,7 @@ int sbm_similarity_local(sbm_ctx* c, int32_t level, int32_t t, int32_t cx, int32
     const int T = c->cfg.T[level], W = c->cols[level] / T, H = c->rows[level] / T;
     DevBuf d;
     if (int e = d.ensure(512)) return e;
-    hipLaunchKernelGGL(k_similarity_local_patch, dim3(1), dim3(256), 0, c->stream, c->d_lm[level].as<uint8_t>(),
+    hipLaunchKernelGGL(k_similarity_local_patch, dim3(1), dim3(64 * LOCAL_WAVES), 0, c->stream, c->d_lm[level].as<uint8_t>(),
                        c->lm_stride[level], c->rows[level], c->cols[level], T, W, H, c->h_tls[(size_t)t * c->L + level], c->d_fxy.as<uint32_t>(),
                        c->d_foff.as<int32_t>(), cx, cy, d.as<uint16_t>());
     int rc = 0;

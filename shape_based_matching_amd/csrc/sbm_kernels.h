@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/sbm_types.h"
 
 namespace sbm {
@@ -121,11 +122,15 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t* __restrict__ im
     const int R0 = blockIdx.y * QT_R, C0 = blockIdx.x * QT_C;
     const bool interior = R0 >= 5 && R0 + QT_R + 5 <= rows && C0 >= 8 && C0 + QT_C + 8 <= cols;
 
-    // ---- A: source tile -> planar LDS ----
-    if (interior) {
-        for (int it = tid; it < QS_R * (QS_W / 4); it += 256) {
-            const int r = it / (QS_W / 4), g = it - r * (QS_W / 4);
-            const uint8_t* p = img + (size_t)(R0 - 5 + r) * stride + (size_t)(C0 - 8 + 4 * g) * CH;
+    // ---- A: source tile -> planar LDS (rows clamped; a 4-pixel group that sticks out of the image
+    //         left or right takes the per-byte clamped path = BORDER_REPLICATE) ----
+    for (int it = tid; it < QS_R * (QS_W / 4); it += 256) {
+        const int r = it / (QS_W / 4), g = it - r * (QS_W / 4);
+        const int gr = clampi(R0 - 5 + r, 0, rows - 1);
+        const int c = C0 - 8 + 4 * g;
+        const uint8_t* rowp = img + (size_t)gr * stride;
+        if (c >= 0 && c + 4 <= cols) {
+            const uint8_t* p = rowp + (size_t)c * CH;
             if (CH == 1) {
                 s_src[0][r][g] = ld_u32_any(p);
             } else {
@@ -135,14 +140,14 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t* __restrict__ im
                 s_src[1 % CH][r][g] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c070401u), 0x06020100u);
                 s_src[2 % CH][r][g] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c0c0502u), 0x07040100u);
             }
-        }
-    } else {
-        uint8_t* sb = (uint8_t*)&s_src[0][0][0];
-        for (int it = tid; it < CH * QS_R * QS_W; it += 256) {
-            const int k = it / (QS_R * QS_W), rem = it - k * (QS_R * QS_W);
-            const int r = rem / QS_W, c = rem - r * QS_W;
-            const int gr = clampi(R0 - 5 + r, 0, rows - 1), gc = clampi(C0 - 8 + c, 0, cols - 1);
-            sb[it] = img[(size_t)gr * stride + gc * CH + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) w |= (uint32_t)rowp[clampi(c + m, 0, cols - 1) * CH + k] << (8 * m);
+                s_src[k][r][g] = w;
+            }
         }
     }
     __syncthreads();
@@ -153,26 +158,47 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t* __restrict__ im
         const int oy = (R0 >> 1) + yy, ox = (C0 >> 1) + xx;
         const int drows = rows >> 1, dcols = cols >> 1;
         if (oy < drows && ox < dcols) {
-            int ri[5], ci[5];
+            const bool inner = 2 * oy >= 2 && 2 * oy + 2 < rows && 2 * ox >= 2 && 2 * ox + 2 < cols;
+            int accs[CH];
+            if (inner) { // taps are 5 consecutive bytes of 5 consecutive tile rows: v_dot4 + 1
+                const int r0t = 2 * yy + 3;      // tile row of image row 2*oy - 2
+                const int b0 = 2 * xx + 6;       // tile byte column of image col 2*ox - 2 (even: shift 0 or 2)
+                const int w = b0 >> 2, sh = b0 & 3;
+                const int K5[5] = {1, 4, 6, 4, 1};
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                ri[j] = reflect101(2 * oy + j - 2, rows) - (R0 - 5);
-                ci[j] = reflect101(2 * ox + j - 2, cols) - (C0 - 8);
-            }
-            const int K5[5] = {1, 4, 6, 4, 1};
+                for (int k = 0; k < CH; ++k) {
+                    int acc = 0;
 #pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const uint8_t* sb = (const uint8_t*)&s_src[k][0][0];
-                int acc = 0;
+                    for (int j = 0; j < 5; ++j) {
+                        const uint32_t d0 = s_src[k][r0t + j][w], d1 = s_src[k][r0t + j][w + 1];
+                        const uint32_t lo4 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                        const uint32_t b4 = (d1 >> (8 * sh)) & 0xffu;
+                        acc += K5[j] * (int)(__builtin_amdgcn_udot4(lo4, 0x04060401u, b4, false));
+                    }
+                    accs[k] = acc;
+                }
+            } else {
+                int ri[5], ci[5];
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
-                    int h = 0;
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) h += K5[i] * sb[ri[j] * QS_W + ci[i]];
-                    acc += K5[j] * h;
+                    ri[j] = reflect101(2 * oy + j - 2, rows) - (R0 - 5);
+                    ci[j] = reflect101(2 * ox + j - 2, cols) - (C0 - 8);
                 }
-                pyr_out[((size_t)oy * dcols + ox) * CH + k] = (uint8_t)((acc + 128) >> 8);
+                const int K5[5] = {1, 4, 6, 4, 1};
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const uint8_t* sb = (const uint8_t*)&s_src[k][0][0];
+                    int acc = 0;
+                    for (int j = 0; j < 5; ++j) {
+                        int h = 0;
+                        for (int i = 0; i < 5; ++i) h += K5[i] * sb[ri[j] * QS_W + ci[i]];
+                        acc += K5[j] * h;
+                    }
+                    accs[k] = acc;
+                }
             }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) pyr_out[((size_t)oy * dcols + ox) * CH + k] = (uint8_t)((accs[k] + 128) >> 8);
         }
     }
 
@@ -668,6 +694,8 @@ __device__ __forceinline__ void accumulate_features(const uint8_t* __restrict__ 
     uint32_t acc = 0;
     lo = hi = 0;
     int pending = 0;
+    count = __builtin_amdgcn_readfirstlane(count); // wave-uniform by contract: keep the loop control scalar
+    f0 = __builtin_amdgcn_readfirstlane(f0);
     for (int b = 0; b < count; b += 64) {
         int sel = -1;
         if (b + lane < count) {
@@ -676,23 +704,31 @@ __device__ __forceinline__ void accumulate_features(const uint8_t* __restrict__ 
             if (x >= 0 && y >= 0 && x < cols && y < rows) sel = foff[f0 + b + lane];
         }
         const int nb = count - b < 64 ? count - b : 64;
-        for (int u = 0; u < nb; u += FB) {
-            uint32_t v[FB];
+        // straight-line batches (no branches between the loads of a batch, so all of a batch's
+        // loads are in flight together); the tail runs as batches of 4, 2, 1: no padding loads
+        auto batch = [&](auto N, int u) {
+            constexpr int n = decltype(N)::value;
+            uint32_t v[n];
 #pragma unroll
-            for (int k = 0; k < FB; ++k) {
+            for (int k = 0; k < n; ++k) {
                 const int o = __builtin_amdgcn_readlane(sel, (u + k) & 63);
                 v[k] = ld_u32_any(o >= 0 ? p_ok + o : p_zero);
             }
 #pragma unroll
-            for (int k = 0; k < FB; ++k) acc += v[k];
-            pending += FB;
+            for (int k = 0; k < n; ++k) acc += v[k];
+            pending += n;
             if (pending + FB > 63) {
                 lo += acc & 0x00ff00ffu;
                 hi += (acc >> 8) & 0x00ff00ffu;
                 acc = 0;
                 pending = 0;
             }
-        }
+        };
+        int u = 0;
+        for (; u + FB <= nb; u += FB) batch(std::integral_constant<int, FB>{}, u);
+        if (nb - u >= 4) { batch(std::integral_constant<int, 4>{}, u); u += 4; }
+        if (nb - u >= 2) { batch(std::integral_constant<int, 2>{}, u); u += 2; }
+        if (nb - u >= 1) batch(std::integral_constant<int, 1>{}, u);
     }
     lo += acc & 0x00ff00ffu;
     hi += (acc >> 8) & 0x00ff00ffu;
@@ -722,6 +758,7 @@ __device__ __forceinline__ void accumulate_features16(const uint8_t* __restrict_
 #pragma unroll
     for (int i = 0; i < 4; ++i) lo[i] = hi[i] = 0;
     int pending = 0;
+    count = __builtin_amdgcn_readfirstlane(count); // wave-uniform by contract: keep the loop control scalar
     for (int b = 0; b < count; b += 64) {
         int sel = zero_off;
         if (b + lane < count) {
@@ -730,26 +767,27 @@ __device__ __forceinline__ void accumulate_features16(const uint8_t* __restrict_
             if (x < cols && y < rows) sel = foff[b + lane];
         }
         const int nb = count - b < 64 ? count - b : 64;
-        for (int u = 0; u < nb; u += FB) {
-            u128_a4 q[FB];
-            uint32_t e[FB];
-            int sh[FB];
+        auto batch = [&](auto N, int u) {
+            constexpr int n = decltype(N)::value;
+            u128_a4 q[n];
+            uint32_t e[n];
+            int sh[n];
 #pragma unroll
-            for (int k = 0; k < FB; ++k) {
-                const int o = (u + k < nb) ? __builtin_amdgcn_readlane(sel, (u + k) & 63) : zero_off;
+            for (int k = 0; k < n; ++k) {
+                const int o = __builtin_amdgcn_readlane(sel, (u + k) & 63);
                 sh[k] = o & 3;
                 const uint8_t* a = p + (o & ~3);
                 q[k] = *(const u128_a4*)a;
                 e[k] = *(const uint32_t*)(a + 16);
             }
 #pragma unroll
-            for (int k = 0; k < FB; ++k) {
+            for (int k = 0; k < n; ++k) {
                 acc[0] += __builtin_amdgcn_alignbyte(q[k].y, q[k].x, sh[k]);
                 acc[1] += __builtin_amdgcn_alignbyte(q[k].z, q[k].y, sh[k]);
                 acc[2] += __builtin_amdgcn_alignbyte(q[k].w, q[k].z, sh[k]);
                 acc[3] += __builtin_amdgcn_alignbyte(e[k], q[k].w, sh[k]);
             }
-            pending += FB;
+            pending += n;
             if (pending + FB > 63) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -759,7 +797,12 @@ __device__ __forceinline__ void accumulate_features16(const uint8_t* __restrict_
                 }
                 pending = 0;
             }
-        }
+        };
+        int u = 0;
+        for (; u + FB <= nb; u += FB) batch(std::integral_constant<int, FB>{}, u);
+        if (nb - u >= 4) { batch(std::integral_constant<int, 4>{}, u); u += 4; }
+        if (nb - u >= 2) { batch(std::integral_constant<int, 2>{}, u); u += 2; }
+        if (nb - u >= 1) batch(std::integral_constant<int, 1>{}, u);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -775,16 +818,21 @@ __global__ void k_reset(int32_t* __restrict__ counters, int32_t* __restrict__ ou
     if (threadIdx.x < 2) out_count[threadIdx.x] = 0;
 }
 
-// grid = (position chunks of 1024, active templates), one wave per block, 16
-// positions per lane.  Fused threshold scan: no score map is written;
+// grid = (position chunks of 1024, active templates); block = 4 waves.  Every
+// wave covers the same 1024 positions (16 per lane) for a contiguous quarter
+// of the template's features, so four times as many loads are in flight per
+// position chunk; the partial sums meet in LDS and each wave then scans a
+// quarter of the positions.  Fused threshold scan: no score map is written;
 // candidates are appended with an atomic counter.
 constexpr int COARSE_POS_PER_BLOCK = 1024;
-__global__ __launch_bounds__(64) void k_similarity_coarse(
+__global__ __launch_bounds__(256) void k_similarity_coarse(
     const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int lc,
     const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
     const int32_t* __restrict__ active, const int32_t* __restrict__ raw_min, Cand* __restrict__ cands,
     int32_t* __restrict__ counters, int cap)
 {
+    __shared__ uint32_t s_red[4][8][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = active[blockIdx.y];
     const DevTL tl = tls[(size_t)t * L + lc];
     const int npos = template_positions(tl, W, H, T);
@@ -793,38 +841,40 @@ __global__ __launch_bounds__(64) void k_similarity_coarse(
     const int total = W * H;
     if (base >= total) return;
     if (base >= npos && rmin > 0) return; // beyond the span every score is 0
-    const int j0 = base + threadIdx.x * 16;
+    const int j0 = base + lane * 16;
     uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
     if (base < npos) { // block-uniform: every lane takes part (features are spread over the wave's lanes)
         const int zero_off = (int)(7 * lm_stride + (int64_t)T * T * W * H); // zero tail of the last orientation
         const int jl = j0 < npos ? j0 : 0; // lanes past the span load valid bytes and discard them
-        accumulate_features16(lm, fxy + tl.feat_off, foff + tl.feat_off, tl.nf, rows, cols, jl, zero_off, lo, hi);
+        const int chunk = (tl.nf + 3) >> 2;
+        const int f0 = wave * chunk;
+        int cnt = tl.nf - f0;
+        cnt = cnt < 0 ? 0 : (cnt > chunk ? chunk : cnt);
+        accumulate_features16(lm, fxy + tl.feat_off + f0, foff + tl.feat_off + f0, cnt, rows, cols, jl, zero_off, lo, hi);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s_red[wave][i][lane] = lo[i];
+        s_red[wave][4 + i][lane] = hi[i];
+    }
+    __syncthreads();
+    // wave w scans positions j0 + 4w .. j0 + 4w + 3 of every lane
+    const uint32_t slo = s_red[0][wave][lane] + s_red[1][wave][lane] + s_red[2][wave][lane] + s_red[3][wave][lane];
+    const uint32_t shi = s_red[0][4 + wave][lane] + s_red[1][4 + wave][lane] + s_red[2][4 + wave][lane] + s_red[3][4 + wave][lane];
     const int offset = T / 2 + (T % 2 - 1);
-    bool any = false;
-    int raws[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = j0 + 4 * i + k;
-            int raw = unpack4(lo[i], hi[i], k);
-            if (j >= npos) raw = 0;
-            raws[4 * i + k] = raw;
-            any |= (j < total && raw >= rmin);
-        }
-    if (!any) return;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int j = j0 + m;
-        if (j < total && raws[m] >= rmin) {
+    for (int k = 0; k < 4; ++k) {
+        const int j = j0 + 4 * wave + k;
+        int raw = unpack4(slo, shi, k);
+        if (j >= npos) raw = 0;
+        if (j < total && raw >= rmin) {
             int idx = atomicAdd(&counters[0], 1);
             if (idx < cap) {
                 Cand c;
                 c.t = t;
                 c.x = (j % W) * T + offset;
                 c.y = (j / W) * T + offset;
-                c.raw = raws[m];
+                c.raw = raw;
                 cands[idx] = c;
             }
         }
@@ -856,35 +906,40 @@ __global__ __launch_bounds__(256) void k_similarity_map(const uint8_t* __restric
 }
 
 // 16x16 patch of one candidate: lane = (row = lane>>2, 4 columns); the block's
-// 4 waves each take a contiguous quarter of the features and the partial sums
-// meet in LDS.  Result (packed u16) valid in wave 0.
+// LOCAL_WAVES waves each take a contiguous slice of the features and the partial
+// sums meet in LDS.  Result (packed u16) valid in wave 0.
+constexpr int LOCAL_WAVES = 16;
 __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int64_t lm_stride, const DevTL tl,
                                             const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
                                             int rows, int cols, int W, int H, int T, int ox, int oy,
-                                            uint32_t (*s_part)[64][2], uint32_t& lo, uint32_t& hi)
+                                            uint32_t (*s_part)[2][64], uint32_t& lo, uint32_t& hi)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane >> 2, c4 = (lane & 3) * 4;
     const int delta = (oy / T) * W + ox / T + r * W + c4;
     const uint8_t* zero_addr = lm + 7 * lm_stride + (int64_t)T * T * W * H;
-    const int chunk = (tl.nf + 3) >> 2;
+    const int chunk = (tl.nf + LOCAL_WAVES - 1) / LOCAL_WAVES;
     const int f0 = wave * chunk;
     int cnt = tl.nf - f0;
     cnt = cnt < 0 ? 0 : (cnt > chunk ? chunk : cnt);
     accumulate_features(lm, fxy + tl.feat_off, foff + tl.feat_off, f0, cnt, rows, cols, ox, oy, delta, zero_addr, 0, lo, hi);
-    s_part[wave][lane][0] = lo;
-    s_part[wave][lane][1] = hi;
+    s_part[wave][0][lane] = lo;
+    s_part[wave][1][lane] = hi;
     __syncthreads();
     if (wave == 0) {
-        lo = s_part[0][lane][0] + s_part[1][lane][0] + s_part[2][lane][0] + s_part[3][lane][0];
-        hi = s_part[0][lane][1] + s_part[1][lane][1] + s_part[2][lane][1] + s_part[3][lane][1];
+        lo = hi = 0;
+#pragma unroll
+        for (int w = 0; w < LOCAL_WAVES; ++w) {
+            lo += s_part[w][0][lane];
+            hi += s_part[w][1][lane];
+        }
     }
     __syncthreads();
 }
 
-// One block (4 waves) per candidate: refine at level l (line2Dup.cpp:1233-1287),
+// One block (LOCAL_WAVES waves) per candidate: refine at level l (line2Dup.cpp:1233-1287),
 // apply the per-level filter (:1290-1292); at level 0 emit the final Match record.
-__global__ __launch_bounds__(256) void k_similarity_local(
+__global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
     const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int l,
     const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
     const int32_t* __restrict__ raw_keep, const int32_t* __restrict__ class_idx,
@@ -892,7 +947,7 @@ __global__ __launch_bounds__(256) void k_similarity_local(
     int cand_cap, int is_last, sbm_match_rec* __restrict__ out, int32_t* __restrict__ out_count,
     int out_cap)
 {
-    __shared__ uint32_t s_part[4][64][2];
+    __shared__ uint32_t s_part[LOCAL_WAVES][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int n = counters[0];
     if (blockIdx.x == 0 && threadIdx.x == 0 && is_last) out_count[1] = n > cand_cap ? 1 : 0; // overflow status
@@ -963,13 +1018,13 @@ __global__ __launch_bounds__(256) void k_similarity_local(
 }
 
 // stage entry point: one 16x16 patch
-__global__ __launch_bounds__(256) void k_similarity_local_patch(const uint8_t* __restrict__ lm, int64_t lm_stride,
+__global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local_patch(const uint8_t* __restrict__ lm, int64_t lm_stride,
                                                                 int rows, int cols, int T, int W, int H, DevTL tl,
                                                                 const uint32_t* __restrict__ fxy,
                                                                 const int32_t* __restrict__ foff, int cx, int cy,
                                                                 uint16_t* __restrict__ dst)
 {
-    __shared__ uint32_t s_part[4][64][2];
+    __shared__ uint32_t s_part[LOCAL_WAVES][2][64];
     const int ox = (cx / T - 8) * T, oy = (cy / T - 8) * T;
     uint32_t lo, hi;
     local_patch(lm, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi);
