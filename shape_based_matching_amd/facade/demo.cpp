@@ -1,0 +1,91 @@
+// demo.cpp — command-line driver over the drop-in line2Dup::Detector facade, in the
+// shape of the reference's test.cpp:angle_test (test.cpp:262-420) without highgui:
+//   demo match <templ_fmt> <class_id> <image.ppm|.pgm> <threshold> <num_features> [pad]
+//       readClasses + (optional zero padding, crop to multiples of 16) + match; prints the matches
+//   demo train <image.ppm> <mask.pgm> <num_features> <n_rot> <angle_step> <templ_fmt> <class_id> [info.yaml]
+//       addTemplate (angle 0) + addTemplate_rotate for the remaining angles + writeClasses
+//   demo convert <in_fmt> <class_id> <out_fmt>
+//       readClasses + writeClasses (no GPU needed)
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+
+#include "../../include/line2Dup.h"
+
+using namespace cv;
+
+static int usage()
+{
+    fprintf(stderr, "usage: demo match|train ... (see demo.cpp)\n");
+    return 2;
+}
+
+int main(int argc, char** argv)
+{
+    try {
+        if (argc < 2) return usage();
+        const std::string mode = argv[1];
+        if (mode == "match") {
+            if (argc < 7) return usage();
+            const std::string fmt = argv[2], class_id = argv[3], path = argv[4];
+            const float threshold = (float)atof(argv[5]);
+            const int num_features = atoi(argv[6]);
+            const int pad = argc > 7 ? atoi(argv[7]) : 0;
+            line2Dup::Detector detector(num_features, {4, 8});
+            std::vector<std::string> ids{class_id};
+            detector.readClasses(ids, fmt);
+            Mat test_img = imread(path, IMREAD_UNCHANGED);
+            if (test_img.empty()) { fprintf(stderr, "cannot read %s\n", path.c_str()); return 1; }
+            // test.cpp:344-353: pad, then crop to multiples of 16
+            Mat padded(test_img.rows + 2 * pad, test_img.cols + 2 * pad, test_img.type(), Scalar::all(0));
+            Mat inner = padded(Rect(pad, pad, test_img.cols, test_img.rows));
+            test_img.copyTo(inner);
+            const int stride = 16;
+            Mat img = padded(Rect(0, 0, stride * (padded.cols / stride), stride * (padded.rows / stride))).clone();
+            std::vector<line2Dup::Match> matches = detector.match(img, threshold, ids);
+            printf("matches %zu templates %d image %dx%dx%d\n", matches.size(), detector.numTemplates(), img.rows, img.cols, img.channels());
+            for (const auto& m : matches) {
+                uint32_t bits;
+                memcpy(&bits, &m.similarity, 4);
+                printf("%d %d %u %s %d\n", m.x, m.y, bits, m.class_id.c_str(), m.template_id);
+            }
+            return 0;
+        }
+        if (mode == "train") {
+            if (argc < 9) return usage();
+            Mat img = imread(argv[2], IMREAD_UNCHANGED), mask = imread(argv[3], IMREAD_GRAYSCALE);
+            const int num_features = atoi(argv[4]), n_rot = atoi(argv[5]);
+            const float angle_step = (float)atof(argv[6]);
+            const std::string fmt = argv[7], class_id = argv[8];
+            if (img.empty() || mask.empty()) { fprintf(stderr, "cannot read inputs\n"); return 1; }
+            line2Dup::Detector detector(num_features, {4, 8});
+            shape_based_matching::shapeInfo_producer shapes(img, mask);
+            std::vector<shape_based_matching::shapeInfo_producer::Info> infos;
+            int first_id = detector.addTemplate(shapes.src, class_id, shapes.mask); // test.cpp:304
+            if (first_id < 0) { fprintf(stderr, "addTemplate failed\n"); return 1; }
+            infos.emplace_back(0.f, 1.f);
+            for (int k = 1; k <= n_rot; ++k) { // test.cpp:310-312
+                float angle = 0.f;
+                for (int j = 0; j < k; ++j) angle += angle_step; // same float accumulation as produce_infos
+                detector.addTemplate_rotate(class_id, first_id, angle, {shapes.src.cols / 2.0f, shapes.src.rows / 2.0f});
+                infos.emplace_back(angle, 1.f);
+            }
+            detector.writeClasses(fmt);
+            if (argc > 9) shape_based_matching::shapeInfo_producer::save_infos(infos, argv[9]);
+            printf("trained %d templates\n", detector.numTemplates());
+            return 0;
+        }
+        if (mode == "convert") { // readClasses + writeClasses: exercises the YAML subset without a GPU
+            if (argc < 5) return usage();
+            line2Dup::Detector detector(63, {4, 8});
+            detector.readClasses({std::string(argv[3])}, argv[2]);
+            detector.writeClasses(argv[4]);
+            printf("converted %d templates\n", detector.numTemplates());
+            return 0;
+        }
+        return usage();
+    } catch (const std::exception& e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+}

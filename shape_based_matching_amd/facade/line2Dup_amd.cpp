@@ -1,0 +1,708 @@
+// line2Dup_amd.cpp — host implementation of include/line2Dup.h on top of the C
+// ABI of libsbm_hip.so (include/sbm.h).  Everything that touches pixels —
+// quantizedOrientations, pyrDown, spread/response/linearize, similarity,
+// similarityLocal — runs in the HIP kernels; this file is the Detector's
+// bookkeeping (template containers, YAML persistence, training-side feature
+// selection) written against the behaviour of the reference (citations are
+// file:line in ddcr/shape_based_matching).
+#include "../../include/line2Dup.h"
+#include "../../include/sbm.h"
+
+#include <algorithm>
+#include <climits>
+#include <iostream>
+#include <mutex>
+#include <stdexcept>
+
+using namespace cv;
+
+namespace {
+
+void check(int rc, const char* what)
+{
+    if (rc != 0) CV_Error(rc == SBM_ERR_INVALID ? Error::StsBadArg : Error::StsError, std::string(what) + ": " + sbm_last_error());
+}
+
+// A context used for the single-function stage calls of the training path
+// (ColorGradientPyramid::update / pyrDown); created on first use, device 0.
+sbm_ctx* util_ctx()
+{
+    static sbm_ctx* ctx = nullptr;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ctx) {
+        sbm_config cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.n_levels = 1;
+        cfg.T[0] = 4;
+        cfg.weak_threshold = 30.f;
+        cfg.device_id = 0;
+        cfg.max_candidates = 1024;
+        check(sbm_create(&cfg, &ctx), "sbm_create");
+    }
+    return ctx;
+}
+
+int label_of(int quantized) // getLabel, line2Dup.cpp:16-40
+{
+    for (int i = 0; i < 8; ++i)
+        if (quantized == (1 << i)) return i;
+    CV_Error(Error::StsBadArg, "Invalid value of quantized parameter");
+    return -1;
+}
+
+// cropTemplates, line2Dup.cpp:115-161
+Rect crop_templates(std::vector<line2Dup::Template>& templates)
+{
+    int min_x = INT_MAX, min_y = INT_MAX, max_x = INT_MIN, max_y = INT_MIN;
+    for (const auto& t : templates)
+        for (const auto& f : t.features) {
+            const int x = f.x << t.pyramid_level, y = f.y << t.pyramid_level;
+            min_x = std::min(min_x, x);
+            min_y = std::min(min_y, y);
+            max_x = std::max(max_x, x);
+            max_y = std::max(max_y, y);
+        }
+    if (min_x % 2 == 1) --min_x;
+    if (min_y % 2 == 1) --min_y;
+    for (auto& t : templates) {
+        t.width = (max_x - min_x) >> t.pyramid_level;
+        t.height = (max_y - min_y) >> t.pyramid_level;
+        t.tl_x = min_x >> t.pyramid_level;
+        t.tl_y = min_y >> t.pyramid_level;
+        for (auto& f : t.features) {
+            f.x -= t.tl_x;
+            f.y -= t.tl_y;
+        }
+    }
+    return Rect(min_x, min_y, max_x - min_x, max_y - min_y);
+}
+
+} // namespace
+
+namespace line2Dup {
+
+// ---- persistence of Feature / Template (line2Dup.cpp:42-113) ------------------
+void Feature::read(const FileNode& fn)
+{
+    FileNodeIterator it = fn.begin();
+    it >> x >> y >> label;
+}
+
+void Feature::write(FileStorage& fs) const { fs << "[:" << x << y << label << "]"; }
+
+void Template::read(const FileNode& fn)
+{
+    width = fn["width"];
+    height = fn["height"];
+    tl_x = fn["tl_x"];
+    tl_y = fn["tl_y"];
+    sscale = fn["scale"];
+    orientation = fn["orientation"];
+    tagFieldID = fn["tagFieldID"];
+    fn["fiducial_src"] >> fiducial_src;
+    pyramid_level = fn["pyramid_level"];
+    FileNode ff = fn["features"];
+    features.resize(ff.size());
+    size_t i = 0;
+    for (FileNodeIterator it = ff.begin(); it != ff.end(); ++it, ++i) features[i].read(*it);
+}
+
+void Template::write(FileStorage& fs) const
+{
+    fs << "width" << width;
+    fs << "height" << height;
+    fs << "tl_x" << tl_x;
+    fs << "tl_y" << tl_y;
+    fs << "scale" << sscale;
+    fs << "orientation" << orientation;
+    fs << "tagFieldID" << tagFieldID;
+    fs << "fiducial_src" << fiducial_src;
+    fs << "pyramid_level" << pyramid_level;
+    fs << "features" << "[";
+    for (const auto& f : features) f.write(fs);
+    fs << "]";
+}
+
+// ---- ColorGradientPyramid (line2Dup.cpp:406-539) --------------------------------
+ColorGradientPyramid::ColorGradientPyramid(const Mat& _src, const Mat& _mask, float _weak_threshold, size_t _num_features,
+                                           float _strong_threshold)
+    : src(_src), mask(_mask), pyramid_level(0), weak_threshold(_weak_threshold), num_features(_num_features),
+      strong_threshold(_strong_threshold)
+{
+    update();
+}
+
+// quantizedOrientations + hysteresisGradient on the GPU (line2Dup.cpp:313-404, 218-311)
+void ColorGradientPyramid::update()
+{
+    CV_Assert(!src.empty() && src.depth() == CV_8U && (src.channels() == 1 || src.channels() == 3));
+    magnitude.create(src.rows, src.cols, CV_32FC1);
+    angle.create(src.rows, src.cols, CV_8UC1);
+    angle_ori.create(src.rows, src.cols, CV_32FC1);
+    check(sbm_quantized_orientations(util_ctx(), src.data, src.rows, src.cols, (int)src.step, src.channels(), weak_threshold,
+                                     magnitude.ptr<float>(), angle.ptr<uchar>(), angle_ori.ptr<float>()),
+          "sbm_quantized_orientations");
+}
+
+void ColorGradientPyramid::pyrDown()
+{
+    num_features /= 2; // line2Dup.cpp:427
+    ++pyramid_level;
+    Mat next(src.rows / 2, src.cols / 2, src.type());
+    check(sbm_pyrdown(util_ctx(), src.data, src.rows, src.cols, (int)src.step, src.channels(), next.data), "sbm_pyrdown");
+    if (!mask.empty()) { // resize(mask, INTER_NEAREST), line2Dup.cpp:439
+        Mat next_mask(next.rows, next.cols, CV_8UC1);
+        const double fx = (double)mask.cols / next.cols, fy = (double)mask.rows / next.rows;
+        for (int y = 0; y < next.rows; ++y) {
+            const int sy = std::min((int)std::floor(y * fy), mask.rows - 1);
+            for (int x = 0; x < next.cols; ++x) next_mask.ptr(y)[x] = mask.ptr(sy)[std::min((int)std::floor(x * fx), mask.cols - 1)];
+        }
+        mask = next_mask;
+    }
+    src = next;
+    update();
+}
+
+void ColorGradientPyramid::quantize(Mat& dst) const
+{
+    dst = Mat::zeros(angle.size(), CV_8UC1);
+    angle.copyTo(dst, mask);
+}
+
+// selectScatteredFeatures, line2Dup.cpp:163-212: sweep the (score-sorted) candidates keeping
+// those at least `distance` from every kept feature; grow the distance while a sweep still
+// yields enough features, then shrink it (keeping what was chosen) until enough or distance < 3.
+bool ColorGradientPyramid::selectScatteredFeatures(const std::vector<Candidate>& candidates, std::vector<Feature>& features,
+                                                   size_t num_features, float distance)
+{
+    features.clear();
+    if (candidates.empty()) return true;
+    bool growing = true;
+    for (;;) {
+        const float d2 = distance * distance;
+        for (const Candidate& c : candidates) {
+            bool far_enough = true;
+            for (size_t j = 0; j < features.size() && far_enough; ++j) {
+                const int dx = c.f.x - features[j].x, dy = c.f.y - features[j].y;
+                far_enough = (float)(dx * dx + dy * dy) >= d2;
+            }
+            if (far_enough) features.push_back(c.f);
+        }
+        const bool enough = features.size() >= num_features;
+        if (growing) {
+            if (enough) {
+                features.clear();
+                distance += 1.0f;
+                continue;
+            }
+            growing = false;
+        }
+        distance -= 1.0f;
+        if (enough || distance < 3) break;
+    }
+    return true;
+}
+
+// extractTemplate, line2Dup.cpp:452-539
+bool ColorGradientPyramid::extractTemplate(Template& templ) const
+{
+    const int rows = magnitude.rows, cols = magnitude.cols;
+    Mat local_mask;
+    if (!mask.empty()) { // erode 3x3, BORDER_REPLICATE
+        local_mask.create(rows, cols, CV_8UC1);
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < cols; ++c) {
+                uchar m = 255;
+                for (int dr = -1; dr <= 1; ++dr)
+                    for (int dc = -1; dc <= 1; ++dc)
+                        m = std::min(m, mask.ptr(std::min(std::max(r + dr, 0), rows - 1))[std::min(std::max(c + dc, 0), cols - 1)]);
+                local_mask.ptr(r)[c] = m;
+            }
+    }
+    std::vector<Candidate> candidates;
+    const float threshold_sq = strong_threshold * strong_threshold;
+    Mat valid(rows, cols, CV_8UC1, Scalar(255));
+    for (int r = 2; r < rows - 2; ++r)
+        for (int c = 2; c < cols - 2; ++c) {
+            if (!local_mask.empty() && !local_mask.ptr(r)[c]) continue;
+            float score = 0;
+            if (valid.ptr(r)[c] > 0) { // 5x5 non-maximum suppression on the squared magnitude
+                score = magnitude.at<float>(r, c);
+                bool is_max = true;
+                for (int dr = -2; dr <= 2 && is_max; ++dr)
+                    for (int dc = -2; dc <= 2; ++dc) {
+                        if (dr == 0 && dc == 0) continue;
+                        if (score < magnitude.at<float>(r + dr, c + dc)) {
+                            score = 0;
+                            is_max = false;
+                            break;
+                        }
+                    }
+                if (is_max)
+                    for (int dr = -2; dr <= 2; ++dr)
+                        for (int dc = -2; dc <= 2; ++dc)
+                            if (dr != 0 || dc != 0) valid.ptr(r + dr)[c + dc] = 0;
+            }
+            const uchar a = angle.ptr(r)[c];
+            if (score > threshold_sq && a > 0) {
+                candidates.push_back(Candidate(c, r, label_of(a), score));
+                candidates.back().f.theta = angle_ori.at<float>(r, c);
+            }
+        }
+    if (candidates.size() < num_features) {
+        if (candidates.size() <= 4) {
+            std::cout << "too few features, abort" << std::endl;
+            return false;
+        }
+        std::cout << "have no enough features, exaustive mode" << std::endl;
+    }
+    std::stable_sort(candidates.begin(), candidates.end());
+    const float distance = static_cast<float>(candidates.size() / num_features + 1);
+    if (!selectScatteredFeatures(candidates, templ.features, num_features, distance)) return false;
+    templ.width = -1;
+    templ.height = -1;
+    templ.pyramid_level = pyramid_level;
+    return true;
+}
+
+// ---- ColorGradient (line2Dup.cpp:541-578) ---------------------------------------
+ColorGradient::ColorGradient() : weak_threshold(30.0f), num_features(63), strong_threshold(60.0f) {}
+ColorGradient::ColorGradient(float w, size_t n, float s) : weak_threshold(w), num_features(n), strong_threshold(s) {}
+std::string ColorGradient::name() const { return "ColorGradient"; }
+void ColorGradient::read(const FileNode& fn)
+{
+    std::string type = fn["type"];
+    CV_Assert(type == "ColorGradient");
+    weak_threshold = fn["weak_threshold"];
+    num_features = (size_t)(int)fn["num_features"];
+    strong_threshold = fn["strong_threshold"];
+}
+void ColorGradient::write(FileStorage& fs) const
+{
+    fs << "type" << "ColorGradient";
+    fs << "weak_threshold" << weak_threshold;
+    fs << "num_features" << int(num_features);
+    fs << "strong_threshold" << strong_threshold;
+}
+
+// ---- Detector (line2Dup.cpp:1054-1599) --------------------------------------------
+Detector* Detector::instance = nullptr;
+
+Detector::Detector() : modality(makePtr<ColorGradient>()), pyramid_levels(2), T_at_level({4, 8}), ctx_(nullptr), templates_dirty_(true), device_id_(0) {}
+Detector::Detector(std::vector<int> T)
+    : modality(makePtr<ColorGradient>()), pyramid_levels((int)T.size()), T_at_level(T), ctx_(nullptr), templates_dirty_(true), device_id_(0)
+{
+}
+Detector::Detector(int num_features, std::vector<int> T, float weak_thresh, float strong_thresh)
+    : modality(makePtr<ColorGradient>(weak_thresh, (size_t)num_features, strong_thresh)), pyramid_levels((int)T.size()), T_at_level(T),
+      ctx_(nullptr), templates_dirty_(true), device_id_(0)
+{
+}
+Detector::Detector(const Detector& o)
+    : modality(makePtr<ColorGradient>(*o.modality)), pyramid_levels(o.pyramid_levels), T_at_level(o.T_at_level),
+      class_templates(o.class_templates), ctx_(nullptr), templates_dirty_(true), device_id_(o.device_id_)
+{
+}
+Detector& Detector::operator=(const Detector& o)
+{
+    if (this != &o) {
+        dropContext();
+        modality = makePtr<ColorGradient>(*o.modality);
+        pyramid_levels = o.pyramid_levels;
+        T_at_level = o.T_at_level;
+        class_templates = o.class_templates;
+        device_id_ = o.device_id_;
+    }
+    return *this;
+}
+Detector::~Detector() { dropContext(); }
+
+void Detector::dropContext()
+{
+    if (ctx_) sbm_destroy(ctx_);
+    ctx_ = nullptr;
+    templates_dirty_ = true;
+}
+
+void Detector::setDevice(int device_id)
+{
+    if (device_id != device_id_) dropContext();
+    device_id_ = device_id;
+}
+
+void Detector::ensureContext() const
+{
+    if (ctx_) return;
+    CV_Assert(pyramid_levels >= 1 && pyramid_levels <= SBM_MAX_LEVELS && (int)T_at_level.size() >= pyramid_levels);
+    sbm_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.n_levels = pyramid_levels;
+    for (int l = 0; l < pyramid_levels; ++l) cfg.T[l] = T_at_level[l];
+    cfg.weak_threshold = modality->weak_threshold;
+    cfg.device_id = device_id_;
+    cfg.max_candidates = 0;
+    check(sbm_create(&cfg, &ctx_), "sbm_create");
+    templates_dirty_ = true;
+}
+
+// flatten the TemplatesMap (map order = the order match() walks the classes, :1127-1129)
+void Detector::uploadTemplates() const
+{
+    std::vector<sbm_template_level> levels;
+    std::vector<sbm_feature> feats;
+    std::vector<int32_t> cls, tid;
+    uploaded_class_order_.clear();
+    for (const auto& kv : class_templates) {
+        const int ci = (int)uploaded_class_order_.size();
+        uploaded_class_order_.push_back(kv.first);
+        for (size_t t = 0; t < kv.second.size(); ++t) {
+            const TemplatePyramid& tp = kv.second[t];
+            CV_Assert((int)tp.size() == pyramid_levels);
+            for (const Template& tm : tp) {
+                if (tm.features.size() >= 8192) CV_Error(Error::StsBadArg, "feature size too large"); // :1195
+                sbm_template_level lv;
+                lv.width = tm.width;
+                lv.height = tm.height;
+                lv.tl_x = tm.tl_x;
+                lv.tl_y = tm.tl_y;
+                lv.pyramid_level = tm.pyramid_level;
+                lv.n_features = (int32_t)tm.features.size();
+                lv.feature_offset = (int64_t)feats.size();
+                for (const Feature& f : tm.features) feats.push_back(sbm_feature{f.x, f.y, f.label});
+                levels.push_back(lv);
+            }
+            cls.push_back(ci);
+            tid.push_back((int32_t)t);
+        }
+    }
+    check(sbm_upload_templates(ctx_, (int32_t)cls.size(), levels.data(), feats.data(), (int64_t)feats.size(), cls.data(), tid.data()),
+          "sbm_upload_templates");
+    templates_dirty_ = false;
+}
+
+std::vector<Match> Detector::match(Mat source, float threshold, const std::vector<std::string>& class_ids, const Mat mask) const
+{
+    std::vector<Match> matches;
+    CV_Assert(mask.empty() || mask.size() == source.size()); // :1086
+    CV_Assert(!source.empty() && source.depth() == CV_8U && (source.channels() == 1 || source.channels() == 3));
+    ensureContext();
+    if (templates_dirty_) uploadTemplates();
+    if (class_templates.empty()) return matches;
+
+    std::vector<int32_t> sel;
+    if (!class_ids.empty()) { // unknown ids are skipped silently (:1136-1138)
+        for (const std::string& id : class_ids) {
+            auto it = std::find(uploaded_class_order_.begin(), uploaded_class_order_.end(), id);
+            if (it != uploaded_class_order_.end()) sel.push_back((int32_t)(it - uploaded_class_order_.begin()));
+        }
+        if (sel.empty()) return matches;
+    }
+    check(sbm_select_classes(ctx_, sel.empty() ? nullptr : sel.data(), (int32_t)sel.size()), "sbm_select_classes");
+
+    Mat mask8;
+    if (!mask.empty()) {
+        CV_Assert(mask.type() == CV_8UC1);
+        mask8 = mask.isContinuous() ? mask : mask.clone();
+    }
+    std::vector<sbm_match_rec> recs(1 << 16);
+    int64_t n = 0;
+    for (;;) {
+        int rc = sbm_match(ctx_, source.data, source.rows, source.cols, (int)source.step, source.channels(),
+                           mask8.empty() ? nullptr : mask8.data, threshold, recs.data(), (int64_t)recs.size(), &n);
+        if (rc == SBM_ERR_CAPACITY && n > (int64_t)recs.size()) {
+            recs.resize((size_t)n);
+            continue;
+        }
+        check(rc, "sbm_match");
+        break;
+    }
+    // epilogue (:1142-1145): canonical sort, exact-duplicate removal, then the reference's own
+    // adjacent std::unique (its operator== ignores template_id)
+    n = sbm_canonicalize(recs.data(), n);
+    matches.reserve((size_t)n);
+    for (int64_t i = 0; i < n; ++i)
+        matches.push_back(Match(recs[i].x, recs[i].y, recs[i].similarity, uploaded_class_order_[recs[i].class_idx], recs[i].template_id));
+    matches.erase(std::unique(matches.begin(), matches.end()), matches.end());
+    return matches;
+}
+
+int Detector::addTemplate(const Mat source, const std::string& class_id, const Mat& object_mask, float sscale, float orientation,
+                          int tagFieldID, std::string fiducial_src, int num_features)
+{
+    std::vector<TemplatePyramid>& template_pyramids = class_templates[class_id];
+    const int template_id = static_cast<int>(template_pyramids.size());
+    TemplatePyramid tp(pyramid_levels);
+    {
+        Ptr<ColorGradientPyramid> qp = modality->process(source, object_mask);
+        if (num_features > 0) qp->num_features = num_features;
+        for (int l = 0; l < pyramid_levels; ++l) {
+            if (l > 0) qp->pyrDown();
+            const bool ok = qp->extractTemplate(tp[l]);
+            tp[l].sscale = sscale;
+            tp[l].orientation = orientation;
+            tp[l].tagFieldID = tagFieldID;
+            tp[l].fiducial_src = fiducial_src;
+            if (!ok) return -1;
+        }
+    }
+    crop_templates(tp);
+    template_pyramids.push_back(tp);
+    templates_dirty_ = true;
+    return template_id;
+}
+
+// addTemplate_rotate, line2Dup.cpp:1395-1451
+int Detector::addTemplate_rotate(const std::string& class_id, int zero_id, float theta, Point2f center)
+{
+    std::vector<TemplatePyramid>& template_pyramids = class_templates[class_id];
+    const int template_id = static_cast<int>(template_pyramids.size());
+    CV_Assert(zero_id >= 0 && zero_id < template_id);
+    const TemplatePyramid base = template_pyramids[zero_id];
+    TemplatePyramid tp(pyramid_levels);
+    const double ang = -theta / 180 * CV_PI;
+    for (int l = 0; l < pyramid_levels; ++l) {
+        if (l > 0) center /= 2;
+        for (const Feature& f : base[l].features) {
+            const Point2f p((float)(f.x + base[l].tl_x), (float)(f.y + base[l].tl_y));
+            const Point2f q = p - center;
+            Point2f r;
+            r.x = (float)(std::cos(ang) * q.x - std::sin(ang) * q.y);
+            r.y = (float)(std::sin(ang) * q.x + std::cos(ang) * q.y);
+            r = r + center;
+            Feature g;
+            g.x = int(r.x + 0.5f);
+            g.y = int(r.y + 0.5f);
+            g.theta = f.theta - theta;
+            while (g.theta > 360) g.theta -= 360;
+            while (g.theta < 0) g.theta += 360;
+            g.label = int(g.theta * 16 / 360 + 0.5f);
+            g.label &= 7;
+            tp[l].features.push_back(g);
+        }
+        tp[l].pyramid_level = l;
+    }
+    crop_templates(tp);
+    template_pyramids.push_back(tp);
+    templates_dirty_ = true;
+    return template_id;
+}
+
+const std::vector<Template>& Detector::getTemplates(const std::string& class_id, int template_id) const
+{
+    auto it = class_templates.find(class_id);
+    CV_Assert(it != class_templates.end());
+    CV_Assert(it->second.size() > size_t(template_id));
+    return it->second[template_id];
+}
+
+int Detector::numTemplates() const
+{
+    int n = 0;
+    for (const auto& kv : class_templates) n += (int)kv.second.size();
+    return n;
+}
+
+int Detector::numTemplates(const std::string& class_id) const
+{
+    auto it = class_templates.find(class_id);
+    return it == class_templates.end() ? 0 : (int)it->second.size();
+}
+
+std::vector<std::string> Detector::classIds() const
+{
+    std::vector<std::string> ids;
+    for (const auto& kv : class_templates) ids.push_back(kv.first);
+    return ids;
+}
+
+void Detector::read(const FileNode& fn)
+{
+    class_templates.clear();
+    pyramid_levels = fn["pyramid_levels"];
+    fn["T"] >> T_at_level;
+    modality = makePtr<ColorGradient>();
+    modality->read(fn);
+    dropContext();
+}
+
+void Detector::write(FileStorage& fs) const
+{
+    fs << "pyramid_levels" << pyramid_levels;
+    fs << "T" << T_at_level;
+    modality->write(fs);
+}
+
+std::string Detector::readClass(const FileNode& fn, const std::string& class_id_override)
+{
+    std::string class_id = class_id_override;
+    if (class_id.empty()) {
+        class_id = (std::string)fn["class_id"];
+        CV_Assert(class_templates.find(class_id) == class_templates.end()); // :1514
+    }
+    std::vector<TemplatePyramid> tps;
+    FileNode tps_fn = fn["template_pyramids"];
+    tps.resize(tps_fn.size());
+    int expected_id = 0;
+    for (FileNodeIterator it = tps_fn.begin(); it != tps_fn.end(); ++it, ++expected_id) {
+        const int template_id = (*it)["template_id"];
+        CV_Assert(template_id == expected_id); // :1532
+        FileNode templates_fn = (*it)["templates"];
+        tps[template_id].resize(templates_fn.size());
+        int idx = 0;
+        for (FileNodeIterator jt = templates_fn.begin(); jt != templates_fn.end(); ++jt) tps[template_id][idx++].read(*jt);
+    }
+    class_templates[class_id] = tps;
+    templates_dirty_ = true;
+    return class_id;
+}
+
+void Detector::writeClass(const std::string& class_id, FileStorage& fs) const
+{
+    auto it = class_templates.find(class_id);
+    CV_Assert(it != class_templates.end());
+    fs << "class_id" << it->first;
+    fs << "pyramid_levels" << pyramid_levels;
+    fs << "template_pyramids" << "[";
+    for (size_t i = 0; i < it->second.size(); ++i) {
+        fs << "{";
+        fs << "template_id" << int(i);
+        fs << "templates" << "[";
+        for (const Template& t : it->second[i]) {
+            fs << "{";
+            t.write(fs);
+            fs << "}";
+        }
+        fs << "]";
+        fs << "}";
+    }
+    fs << "]";
+}
+
+void Detector::readClasses(const std::vector<std::string>& class_ids, const std::string& format)
+{
+    for (const std::string& id : class_ids) {
+        const std::string filename = cv::format(format.c_str(), id.c_str());
+        FileStorage fs(filename, FileStorage::READ);
+        if (!fs.isOpened()) CV_Error(Error::StsBadArg, "cannot open template file " + filename);
+        readClass(fs.root());
+    }
+}
+
+void Detector::writeClasses(const std::string& format) const
+{
+    for (const auto& kv : class_templates) {
+        const std::string filename = cv::format(format.c_str(), kv.first.c_str());
+        FileStorage fs(filename, FileStorage::WRITE);
+        writeClass(kv.first, fs);
+    }
+}
+
+// getInstance, line2Dup.cpp:1355-1393: detector config + "classes" + "templates_dir" from one YAML
+Detector* Detector::getInstance() { return getInstance("model_images/detector_linemod.yaml"); }
+
+Detector* Detector::getInstance(std::string path)
+{
+    if (Detector::instance) return Detector::instance;
+    FileStorage fs(path, FileStorage::READ);
+    if (!fs.isOpened()) {
+        std::cout << "LINEMOD configuration file (" << path << ") not found!" << std::endl;
+        throw std::runtime_error("LINEMOD configuration file not found");
+    }
+    Detector* d = new Detector();
+    d->read(fs.root());
+    std::vector<std::string> ids;
+    FileNode classes_fn = fs["classes"];
+    for (FileNodeIterator it = classes_fn.begin(); it != classes_fn.end(); ++it) ids.push_back((std::string)*it);
+    const std::string dir = (std::string)fs["templates_dir"];
+    d->readClasses(ids, dir + "/%s.yaml");
+    Detector::instance = d;
+    return d;
+}
+
+} // namespace line2Dup
+
+// ---- shapeInfo_producer (line2Dup.h:344-458) ------------------------------------------
+namespace shape_based_matching {
+
+shapeInfo_producer::shapeInfo_producer(cv::Mat src_, cv::Mat mask_)
+{
+    src = src_;
+    mask = mask_.empty() ? cv::Mat(src.size(), CV_8UC1, cv::Scalar(255)) : mask_;
+}
+
+cv::Mat shapeInfo_producer::transform(cv::Mat src, float angle, float scale)
+{
+    if (std::abs(scale - 1.0f) > 1e-6f) CV_Error(cv::Error::StsBadArg, "shapeInfo_producer::transform: only scale 1 is supported");
+    float a = std::fmod(angle, 360.f);
+    if (a < 0) a += 360.f;
+    int quarter = -1;
+    for (int q = 0; q < 4; ++q)
+        if (std::abs(a - 90.f * q) < 1e-4f) quarter = q;
+    if (quarter < 0) CV_Error(cv::Error::StsBadArg, "shapeInfo_producer::transform: only multiples of 90 degrees are supported");
+    if (quarter == 0) return src.clone();
+    const size_t es = src.elemSize();
+    const bool swap = quarter != 2;
+    cv::Mat dst(swap ? src.cols : src.rows, swap ? src.rows : src.cols, src.type());
+    for (int r = 0; r < src.rows; ++r)
+        for (int c = 0; c < src.cols; ++c) {
+            int rr, cc;
+            if (quarter == 1) { rr = c; cc = src.rows - 1 - r; }          // ROTATE_90_CLOCKWISE
+            else if (quarter == 2) { rr = src.rows - 1 - r; cc = src.cols - 1 - c; }
+            else { rr = src.cols - 1 - c; cc = r; }                       // ROTATE_90_COUNTERCLOCKWISE
+            memcpy(dst.ptr(rr) + cc * es, src.ptr(r) + c * es, es);
+        }
+    return dst;
+}
+
+cv::Mat shapeInfo_producer::mask_of(const Info& info)
+{
+    cv::Mat m = transform(mask, info.angle, info.scale);
+    for (int r = 0; r < m.rows; ++r)
+        for (int c = 0; c < m.cols; ++c) m.ptr(r)[c] = m.ptr(r)[c] > 0 ? 255 : 0;
+    return m;
+}
+
+void shapeInfo_producer::produce_infos()
+{
+    infos.clear();
+    CV_Assert(angle_range.size() <= 2 && scale_range.size() <= 2);
+    CV_Assert(angle_step > eps * 10 && scale_step > eps * 10);
+    if (angle_range.empty()) angle_range.push_back(0);
+    if (scale_range.empty()) scale_range.push_back(1);
+    const bool a2 = angle_range.size() == 2, s2 = scale_range.size() == 2;
+    if (s2) CV_Assert(scale_range[1] > scale_range[0]);
+    if (a2) CV_Assert(angle_range[1] > angle_range[0]);
+    // float accumulation on purpose: the reference's loops are `for (v = lo; v <= hi + eps; v += step)`
+    for (float scale = scale_range[0]; scale <= (s2 ? scale_range[1] : scale_range[0]) + eps; scale += scale_step) {
+        for (float angle = angle_range[0]; angle <= (a2 ? angle_range[1] : angle_range[0]) + eps; angle += angle_step) {
+            infos.emplace_back(angle, scale);
+            if (!a2) break;
+        }
+        if (!s2) break;
+    }
+}
+
+void shapeInfo_producer::save_infos(std::vector<Info>& infos, std::string path)
+{
+    cv::FileStorage fs(path, cv::FileStorage::WRITE);
+    fs << "infos" << "[";
+    for (const Info& i : infos) {
+        fs << "{";
+        fs << "angle" << i.angle;
+        fs << "scale" << i.scale;
+        fs << "}";
+    }
+    fs << "]";
+}
+
+std::vector<shapeInfo_producer::Info> shapeInfo_producer::load_infos(std::string path)
+{
+    cv::FileStorage fs(path, cv::FileStorage::READ);
+    std::vector<Info> infos;
+    cv::FileNode n = fs["infos"];
+    for (cv::FileNodeIterator it = n.begin(); it != n.end(); ++it) infos.emplace_back((float)(*it)["angle"], (float)(*it)["scale"]);
+    return infos;
+}
+
+} // namespace shape_based_matching
