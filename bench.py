@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="frames in flight per GPU: independent contexts + streams used round-robin")
     args = ap.parse_args()
 
     import torch
@@ -115,31 +117,49 @@ def main():
     ts, frame = load_workload(world)
     first, count = sharding.partition(sharding.coarse_work(ts, ROWS, COLS, T_LEVELS), world)[rank]
 
-    ctx = capi.Context(T=T_LEVELS, weak_threshold=30.0, device_id=local_rank)
-    ctx.upload_templates(ts)
-    ctx.select_range(first, count)
-
-    d_img = torch.from_numpy(frame).to(dev)
     cap = PREFETCH
-    d_out = torch.zeros(cap * MATCH_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    d_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
-    gath_out = torch.zeros(world * cap * MATCH_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    gath_cnt = torch.zeros(world * 2, dtype=torch.int32, device=dev)
-    h_out = torch.zeros(world * cap * MATCH_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
-    h_cnt = torch.zeros(world * 2, dtype=torch.int32).pin_memory()
-    stream = torch.cuda.current_stream()
+    d_img = torch.from_numpy(frame).to(dev)
+
+    class Slot:
+        """one frame in flight: its own engine context (device buffers), stream and result buffers"""
+
+        def __init__(self, main_stream):
+            self.ctx = capi.Context(T=T_LEVELS, weak_threshold=30.0, device_id=local_rank)
+            self.ctx.upload_templates(ts)
+            self.ctx.select_range(first, count)
+            # always an explicit stream: handle 0 would mean "the context's own stream" to the C ABI and
+            # the result copies below must be ordered after the kernels
+            self.stream = torch.cuda.Stream(device=dev)
+            self.d_out = torch.zeros(cap * MATCH_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            self.d_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+            self.gath_out = torch.zeros(world * cap * MATCH_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            self.gath_cnt = torch.zeros(world * 2, dtype=torch.int32, device=dev)
+            self.h_out = torch.zeros(world * cap * MATCH_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
+            self.h_cnt = torch.zeros(world * 2, dtype=torch.int32).pin_memory()
+
+            if world == 1:
+                # single GPU: the last kernel stores the match list straight into pinned host memory
+                self.ctx.set_result_mirror(self.h_out.data_ptr(), self.h_cnt.data_ptr())
+
+        def run(self):
+            with torch.cuda.stream(self.stream):
+                self.ctx.match_device(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, self.d_out.data_ptr(), cap,
+                                      self.d_cnt.data_ptr(), stream=self.stream.cuda_stream)
+                if world > 1:
+                    dist.all_gather_into_tensor(self.gath_cnt, self.d_cnt)
+                    dist.all_gather_into_tensor(self.gath_out, self.d_out)
+                    self.h_cnt.copy_(self.gath_cnt, non_blocking=True)
+                    self.h_out.copy_(self.gath_out, non_blocking=True)
+
+    slots = [Slot(None) for i in range(max(1, args.inflight))]
+    ctx, h_cnt, h_out, d_out, d_cnt = slots[0].ctx, slots[0].h_cnt, slots[0].h_out, slots[0].d_out, slots[0].d_cnt
+    stream = slots[0].stream
+    torch.cuda.synchronize()
+    step_no = [0]
 
     def step():
-        ctx.match_device(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, d_out.data_ptr(), cap,
-                         d_cnt.data_ptr(), stream=stream.cuda_stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gath_cnt, d_cnt)
-            dist.all_gather_into_tensor(gath_out, d_out)
-            h_cnt.copy_(gath_cnt, non_blocking=True)
-            h_out.copy_(gath_out, non_blocking=True)
-        else:
-            h_cnt.copy_(d_cnt, non_blocking=True)
-            h_out.copy_(d_out, non_blocking=True)
+        slots[step_no[0] % len(slots)].run()
+        step_no[0] += 1
 
     def fence():
         torch.cuda.synchronize()
@@ -160,7 +180,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # the match list of the last step, as the host sees it
+    # every slot must hold the same, stable match list (checked outside the timed region)
+    ref_counts = None
+    for rep in range(3):
+        for sl in slots:
+            sl.h_cnt.zero_()
+            sl.run()
+            torch.cuda.synchronize()
+            c = sl.h_cnt.numpy().reshape(world, 2).copy()
+            if ref_counts is None:
+                ref_counts = c
+            if not np.array_equal(c, ref_counts) or c[:, 0].min() <= 0:
+                raise SystemExit(f"unstable match counts: {c.tolist()} vs {ref_counts.tolist()}")
     counts = h_cnt.numpy().reshape(world, 2)
     if (counts[:, 1] != 0).any() or (counts[:, 0] > cap).any():
         raise SystemExit(f"match list overflow: {counts.tolist()}")
@@ -233,6 +264,7 @@ def main():
                 "templates_per_gpu": count,
                 "frame": [ROWS, COLS, 3],
                 "parallelism": f"template-shard x{world}" + (" + RCCL all-gather of match lists" if world > 1 else ""),
+                "frames_in_flight": len(slots),
                 "matches_distinct": n_matches,
                 "coarse_candidates_rank0": n_cand,
             },
@@ -253,7 +285,8 @@ def main():
             base_ts = ts.subset(range(first, first + count))
             out["cpu_baseline"] = cpu_baseline(base_ts, frame, args.cpu_budget)
         print(json.dumps(out))
-    ctx.close()
+    for sl in slots:
+        sl.ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -97,6 +97,22 @@ int sbm_match_device(sbm_ctx* ctx, const void* d_img, int32_t rows, int32_t cols
                      int32_t channels, const void* d_mask, float threshold, void* d_out,
                      int64_t cap, void* d_count, void* stream);
 
+/* sbm_match_device records its kernel sequence once per distinct argument tuple
+ * as a hipGraph (two branches: the fine levels' linear memories are built
+ * while the coarse-level chain runs) and replays it with one hipGraphLaunch per
+ * frame.  enabled = 0 falls back to plain stream launches (also used whenever
+ * profiling is on).  Default: enabled. */
+int sbm_set_graph_mode(sbm_ctx* ctx, int32_t enabled);
+
+/* Optional second destination for the results of sbm_match_device /
+ * sbm_match_templates: every match record (up to the call's cap) and the final
+ * {n_matches, overflow} pair are ALSO stored, with plain stores from the last
+ * kernel, at these device-visible addresses — typically pinned host memory
+ * (hipHostMalloc / torch pin_memory), so the match list reaches the host with
+ * no copy-engine operation after the kernels.  Pass NULL, NULL to disable.  The
+ * mirror must hold cap records / two int32 and outlive the calls using it. */
+int sbm_set_result_mirror(sbm_ctx* ctx, void* mirror_out, void* mirror_count);
+
 /* Detector::match epilogue (line2Dup.cpp:1142-1145) in canonical form: sort by
  * (similarity desc, template_id asc, class_idx asc, y asc, x asc), drop exact
  * duplicates.  Host-side, in place; returns the new count. */

@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "sbm_level_dims", "sbm_match_templates", "sbm_quantized_orientations", "sbm_pyrdown", "sbm_spread",
     "sbm_compute_response_maps", "sbm_linearize", "sbm_similarity", "sbm_similarity_local",
     "sbm_set_profiling", "sbm_get_timings", "sbm_coarse_bytes", "sbm_get_stats",
+    "sbm_set_result_mirror", "sbm_set_graph_mode",
 ]
 
 
@@ -89,6 +90,8 @@ def lib() -> C.CDLL:
     L.sbm_get_timings.argtypes = [vp, vp, vp, i32, C.POINTER(i32)]
     L.sbm_coarse_bytes.argtypes = [vp, C.POINTER(i64)]
     L.sbm_get_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.sbm_set_result_mirror.argtypes = [vp, vp, vp]
+    L.sbm_set_graph_mode.argtypes = [vp, i32]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
         if name not in ("sbm_last_error", "sbm_destroy", "sbm_canonicalize"):
@@ -184,6 +187,14 @@ class Context:
                                       C.c_void_p(d_mask) if d_mask else None, C.c_float(threshold),
                                       C.c_void_p(d_out), cap, C.c_void_p(d_count),
                                       C.c_void_p(stream) if stream else None))
+
+    def set_result_mirror(self, mirror_out: int, mirror_count: int):
+        """Device-visible (e.g. pinned host) addresses that receive a copy of every result."""
+        _check(lib().sbm_set_result_mirror(self._h, C.c_void_p(mirror_out) if mirror_out else None,
+                                           C.c_void_p(mirror_count) if mirror_count else None))
+
+    def set_graph_mode(self, on: bool):
+        _check(lib().sbm_set_graph_mode(self._h, 1 if on else 0))
 
     # -- pyramid state ------------------------------------------------------------
     def build_pyramid(self, img: np.ndarray, mask: Optional[np.ndarray] = None):

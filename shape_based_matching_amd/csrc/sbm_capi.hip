@@ -110,7 +110,39 @@ struct sbm_ctx {
 
     // candidates / results
     DevBuf d_cands, d_counters, d_out, d_outcount;
+    sbm_match_rec* mirror_out = nullptr; // optional device-visible mirror of the results (sbm_set_result_mirror)
+    int32_t* mirror_count = nullptr;
     DevBuf d_scratch;
+
+    // hipGraph cache for sbm_match_device (one captured graph per distinct argument tuple)
+    struct GraphEntry {
+        const void* img;
+        int rows, cols, stride, ch;
+        const void* mask;
+        uint32_t thr_bits;
+        void* out;
+        int64_t cap;
+        void* count;
+        void* mo;
+        void* mc;
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        uint64_t last_use;
+    };
+    std::vector<GraphEntry> graphs;
+    uint64_t graph_clock = 0;
+    bool graph_mode = true;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork[SBM_MAX_LEVELS] = {};
+    hipEvent_t ev_join = nullptr;
+    void drop_graphs()
+    {
+        for (auto& g : graphs) {
+            (void)hipGraphExecDestroy(g.exec);
+            (void)hipGraphDestroy(g.graph);
+        }
+        graphs.clear();
+    }
 
     // profiling
     bool profiling = false;
@@ -198,6 +230,7 @@ int ensure_geometry(sbm_ctx* c, int rows, int cols, int channels)
     c->channels = channels;
     c->foff_dirty = true;
     c->levels_valid = 0;
+    c->drop_graphs(); // captured launches hold the old buffer addresses
     return 0;
 }
 
@@ -205,6 +238,7 @@ int ensure_level(sbm_ctx* c, int l, int rows, int cols)
 {
     if (int e = check_level_dims(rows, cols, c->cfg.T[l])) return e;
     if (c->rows[l] == rows && c->cols[l] == cols && c->d_lm[l].p && c->d_quant[l].p) return 0;
+    c->drop_graphs();
     c->rows[l] = rows;
     c->cols[l] = cols;
     c->lm_stride[l] = lm_stride_for(rows, cols, c->cfg.T[l]);
@@ -382,14 +416,19 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
     return 0;
 }
 
-// matchClass over the active templates; results into d_out/d_count (device)
-int enqueue_templates(sbm_ctx* c, hipStream_t s, float threshold, sbm_match_rec* d_out, int64_t cap, int32_t* d_count)
+// host-side preparation of the template loop: validation, integer thresholds, feature offsets.
+// May synchronise (only when something changed); never called inside a stream capture.
+int prepare_templates(sbm_ctx* c, hipStream_t s, float threshold, int64_t cap)
 {
     if (c->n_templates == 0) return fail(SBM_ERR_STATE, "no templates uploaded");
-    if (c->levels_valid < c->L) return fail(SBM_ERR_STATE, "pyramid not built (%d of %d levels)", c->levels_valid, c->L);
     if (cap < 0 || cap > INT32_MAX) return fail(SBM_ERR_INVALID, "bad output capacity");
     if (int e = ensure_thresholds(c, threshold, s)) return e;
-    if (int e = ensure_foff(c, s)) return e;
+    return ensure_foff(c, s);
+}
+
+// coarse pass over the active templates (reset + k_similarity_coarse; single-level pyramids emit here)
+int enqueue_coarse(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap, int32_t* d_count)
+{
     const int L = c->L, lc = L - 1;
     int32_t* counters = c->d_counters.as<int32_t>();
     hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s, counters, d_count);
@@ -411,18 +450,94 @@ int enqueue_templates(sbm_ctx* c, hipStream_t s, float threshold, sbm_match_rec*
         Scope sc(c, s, "k_emit_coarse");
         hipLaunchKernelGGL(k_emit_coarse, dim3(256), dim3(256), 0, s, c->d_cands.as<Cand>(), counters, (int)c->cand_cap,
                            c->d_tls.as<DevTL>(), L, lc, c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(), d_out, d_count,
-                           (int)cap);
+                           (int)cap, c->mirror_out, c->mirror_count);
         HIP_TRY(hipGetLastError());
     }
+    return 0;
+}
+
+// refinement passes, finest level last (emits the match records)
+int enqueue_local(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap, int32_t* d_count)
+{
+    const int L = c->L;
+    int32_t* counters = c->d_counters.as<int32_t>();
     for (int l = L - 2; l >= 0; --l) {
         const int T = c->cfg.T[l], W = c->cols[l] / T, H = c->rows[l] / T;
         Scope sc(c, s, "k_similarity_local");
         hipLaunchKernelGGL(k_similarity_local, dim3(256), dim3(64 * LOCAL_WAVES), 0, s, c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
                            c->rows[l], c->cols[l], T, W, H, L, l, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(), c->d_foff.as<int32_t>(),
                            c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
-                           c->d_cands.as<Cand>(), counters, (int)c->cand_cap, l == 0 ? 1 : 0, d_out, d_count, (int)cap);
+                           c->d_cands.as<Cand>(), counters, (int)c->cand_cap, l == 0 ? 1 : 0, d_out, d_count, (int)cap,
+                           c->mirror_out, c->mirror_count);
         HIP_TRY(hipGetLastError());
     }
+    return 0;
+}
+
+// matchClass over the active templates; results into d_out/d_count (device)
+int enqueue_templates(sbm_ctx* c, hipStream_t s, float threshold, sbm_match_rec* d_out, int64_t cap, int32_t* d_count)
+{
+    if (c->levels_valid < c->L) return fail(SBM_ERR_STATE, "pyramid not built (%d of %d levels)", c->levels_valid, c->L);
+    if (int e = prepare_templates(c, s, threshold, cap)) return e;
+    if (int e = enqueue_coarse(c, s, d_out, cap, d_count)) return e;
+    return enqueue_local(c, s, d_out, cap, d_count);
+}
+
+// The whole match() as a DAG, recorded by stream capture on the context's two private streams:
+//   main: quantize(0) -> quantize(1) -> ... -> quantize(L-1) -> build_lm(L-1) -> coarse -> [join] -> local(L-2..0)
+//   side:          \-> build_lm(0)      \-> build_lm(1) ...                                  /
+// The linear memories of the finer levels are only needed by the refinement passes, so their
+// construction overlaps the coarse-level chain.
+int capture_match_graph(sbm_ctx* c, const uint8_t* d_img0, int stride0, const uint8_t* d_mask0, sbm_match_rec* d_out,
+                        int64_t cap, int32_t* d_count, hipGraph_t* graph)
+{
+    const int ch = c->channels, L = c->L;
+    hipStream_t m = c->stream, sd = c->side;
+    HIP_TRY(hipStreamBeginCapture(m, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    const uint8_t* img = d_img0;
+    int stride = stride0;
+    const uint8_t* mask = d_mask0;
+    bool forked = false;
+    for (int l = 0; l < L && !rc; ++l) {
+        if (l > 0) {
+            if (mask) {
+                const int n = c->rows[l] * c->cols[l];
+                hipLaunchKernelGGL(k_resize_mask, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, m, mask, c->rows[l - 1],
+                                   c->cols[l - 1], c->d_mask[l].as<uint8_t>(), c->rows[l], c->cols[l]);
+                mask = c->d_mask[l].as<uint8_t>();
+            }
+            img = c->d_img[l].as<uint8_t>();
+            stride = c->cols[l] * ch;
+        }
+        rc = launch_quantize(c, m, img, c->rows[l], c->cols[l], stride, ch, mask, c->cfg.weak_threshold, c->d_quant[l].as<uint8_t>(),
+                             nullptr, nullptr, l + 1 < L ? c->d_img[l + 1].as<uint8_t>() : nullptr);
+        if (rc) break;
+        if (l < L - 1) {
+            if (hipEventRecord(c->ev_fork[l], m) != hipSuccess || hipStreamWaitEvent(sd, c->ev_fork[l], 0) != hipSuccess) {
+                rc = fail(SBM_ERR_HIP, "graph fork failed");
+                break;
+            }
+            forked = true;
+            rc = launch_build_lm(c, sd, c->d_quant[l].as<uint8_t>(), c->rows[l], c->cols[l], c->cfg.T[l], c->d_lm[l].as<uint8_t>(), c->lm_stride[l]);
+        } else {
+            rc = launch_build_lm(c, m, c->d_quant[l].as<uint8_t>(), c->rows[l], c->cols[l], c->cfg.T[l], c->d_lm[l].as<uint8_t>(), c->lm_stride[l]);
+        }
+    }
+    if (!rc) rc = enqueue_coarse(c, m, d_out, cap, d_count);
+    if (!rc && forked) {
+        if (hipEventRecord(c->ev_join, sd) != hipSuccess || hipStreamWaitEvent(m, c->ev_join, 0) != hipSuccess)
+            rc = fail(SBM_ERR_HIP, "graph join failed");
+    }
+    if (!rc) rc = enqueue_local(c, m, d_out, cap, d_count);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(m, &g);
+    if (rc) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess || !g) return fail(SBM_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    *graph = g;
     return 0;
 }
 
@@ -484,8 +599,18 @@ int sbm_create(const sbm_config* cfg, sbm_ctx** out)
         delete c;
         return fail(SBM_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        sbm_destroy(c);
+        return fail(SBM_ERR_HIP, "stream/event creation failed");
+    }
+    for (int l = 0; l < SBM_MAX_LEVELS; ++l)
+        if (hipEventCreateWithFlags(&c->ev_fork[l], hipEventDisableTiming) != hipSuccess) {
+            sbm_destroy(c);
+            return fail(SBM_ERR_HIP, "event creation failed");
+        }
     int rc = 0;
-    if ((rc = c->d_cands.ensure((size_t)c->cand_cap * sizeof(Cand))) || (rc = c->d_counters.ensure(16, true)) ||
+    if ((rc = c->d_cands.ensure((size_t)c->cand_cap * sizeof(Cand))) || (rc = c->d_counters.ensure(64, true)) ||
         (rc = c->d_out.ensure((size_t)c->cand_cap * sizeof(sbm_match_rec))) || (rc = c->d_outcount.ensure(16, true))) {
         sbm_destroy(c);
         return rc;
@@ -498,7 +623,12 @@ void sbm_destroy(sbm_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device_id);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();
+    c->drop_graphs();
+    for (int l = 0; l < SBM_MAX_LEVELS; ++l)
+        if (c->ev_fork[l]) (void)hipEventDestroy(c->ev_fork[l]);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side) (void)hipStreamDestroy(c->side);
     c->clear_timings();
     DevBuf* singles[] = {&c->d_tls, &c->d_fxy, &c->d_flabel, &c->d_flevel, &c->d_foff, &c->d_class, &c->d_tid, &c->d_active,
                          &c->d_rawmin, &c->d_rawkeep, &c->d_geo, &c->d_cands, &c->d_counters, &c->d_out, &c->d_outcount,
@@ -577,6 +707,7 @@ int sbm_upload_templates(sbm_ctx* c, int32_t n_templates, const sbm_template_lev
     c->h_tid.swap(tid);
     c->have_thr = false;
     c->foff_dirty = true;
+    c->drop_graphs();
     return sbm_select_classes(c, nullptr, 0);
 }
 
@@ -587,6 +718,7 @@ static int set_active(sbm_ctx* c, std::vector<int32_t>& act)
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!act.empty()) HIP_TRY(hipMemcpy(c->d_active.p, act.data(), act.size() * 4, hipMemcpyHostToDevice));
     c->h_active.swap(act);
+    c->drop_graphs(); // grid sizes depend on the active set
     return 0;
 }
 
@@ -621,10 +753,64 @@ int sbm_match_device(sbm_ctx* c, const void* d_img, int32_t rows, int32_t cols, 
     if (stride < cols * channels) return fail(SBM_ERR_INVALID, "stride %d < cols*channels", stride);
     HIP_TRY(hipSetDevice(c->cfg.device_id));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (!c->graph_mode || c->profiling) {
+        if (int e = ensure_geometry(c, rows, cols, channels)) return e;
+        if (c->profiling) c->clear_timings();
+        if (int e = enqueue_pyramid(c, s, (const uint8_t*)d_img, stride, (const uint8_t*)d_mask)) return e;
+        return enqueue_templates(c, s, threshold, (sbm_match_rec*)d_out, cap, (int32_t*)d_count);
+    }
+    // graph path: all state changes happen up front (they may synchronise), then one hipGraphLaunch
+    uint32_t thr_bits;
+    memcpy(&thr_bits, &threshold, 4);
+    const bool dirty = !(c->channels == channels && c->rows[0] == rows && c->cols[0] == cols && c->levels_valid == c->L) ||
+                       !c->have_thr || memcmp(&threshold, &c->thr_cached, 4) != 0 || c->foff_dirty;
+    if (dirty) HIP_TRY(hipDeviceSynchronize()); // earlier launches may still read what is about to change
     if (int e = ensure_geometry(c, rows, cols, channels)) return e;
-    if (c->profiling) c->clear_timings();
-    if (int e = enqueue_pyramid(c, s, (const uint8_t*)d_img, stride, (const uint8_t*)d_mask)) return e;
-    return enqueue_templates(c, s, threshold, (sbm_match_rec*)d_out, cap, (int32_t*)d_count);
+    if (int e = prepare_templates(c, c->stream, threshold, cap)) return e;
+    sbm_ctx::GraphEntry* hit = nullptr;
+    for (auto& g : c->graphs)
+        if (g.img == d_img && g.rows == rows && g.cols == cols && g.stride == stride && g.ch == channels && g.mask == d_mask &&
+            g.thr_bits == thr_bits && g.out == d_out && g.cap == cap && g.count == d_count && g.mo == (void*)c->mirror_out &&
+            g.mc == (void*)c->mirror_count)
+            hit = &g;
+    if (!hit) {
+        if (c->graphs.size() >= 8) { // evict the least recently used capture
+            size_t lru = 0;
+            for (size_t i = 1; i < c->graphs.size(); ++i)
+                if (c->graphs[i].last_use < c->graphs[lru].last_use) lru = i;
+            HIP_TRY(hipDeviceSynchronize());
+            (void)hipGraphExecDestroy(c->graphs[lru].exec);
+            (void)hipGraphDestroy(c->graphs[lru].graph);
+            c->graphs.erase(c->graphs.begin() + lru);
+        }
+        sbm_ctx::GraphEntry ge{d_img, rows, cols, stride, channels, d_mask, thr_bits, d_out, cap, d_count,
+                               (void*)c->mirror_out, (void*)c->mirror_count, nullptr, nullptr, 0};
+        if (int e = capture_match_graph(c, (const uint8_t*)d_img, stride, (const uint8_t*)d_mask, (sbm_match_rec*)d_out, cap,
+                                        (int32_t*)d_count, &ge.graph))
+            return e;
+        hipError_t he = hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0);
+        if (he != hipSuccess) {
+            (void)hipGraphDestroy(ge.graph);
+            return fail(SBM_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(he));
+        }
+        c->graphs.push_back(ge);
+        hit = &c->graphs.back();
+    }
+    hit->last_use = ++c->graph_clock;
+    c->levels_valid = c->L;
+    HIP_TRY(hipGraphLaunch(hit->exec, s));
+    return 0;
+}
+
+int sbm_set_graph_mode(sbm_ctx* c, int32_t enabled)
+{
+    if (!c) return fail(SBM_ERR_INVALID, "null context");
+    c->graph_mode = enabled != 0;
+    if (!c->graph_mode) {
+        (void)hipDeviceSynchronize();
+        c->drop_graphs();
+    }
+    return 0;
 }
 
 static int upload_image(sbm_ctx* c, const uint8_t* img, int rows, int cols, int stride, int ch, const uint8_t* mask)
@@ -936,6 +1122,14 @@ int sbm_get_stats(sbm_ctx* c, int64_t* n_candidates, int64_t* refine_bytes)
         memcpy(&b, &h[2], sizeof b);
         *refine_bytes = (int64_t)b;
     }
+    return 0;
+}
+
+int sbm_set_result_mirror(sbm_ctx* c, void* mirror_out, void* mirror_count)
+{
+    if (!c || ((mirror_out == nullptr) != (mirror_count == nullptr))) return fail(SBM_ERR_INVALID, "both mirror pointers or neither");
+    c->mirror_out = (sbm_match_rec*)mirror_out;
+    c->mirror_count = (int32_t*)mirror_count;
     return 0;
 }
 

@@ -814,7 +814,7 @@ __device__ __forceinline__ void accumulate_features16(const uint8_t* __restrict_
 // zero the per-call counters (one launch instead of two memsets)
 __global__ void k_reset(int32_t* __restrict__ counters, int32_t* __restrict__ out_count)
 {
-    if (threadIdx.x < 4) counters[threadIdx.x] = 0;
+    if (threadIdx.x < 8) counters[threadIdx.x] = 0; // [0] candidates [1] - [2,3] refine bytes [4] blocks done
     if (threadIdx.x < 2) out_count[threadIdx.x] = 0;
 }
 
@@ -905,6 +905,29 @@ __global__ __launch_bounds__(256) void k_similarity_map(const uint8_t* __restric
     }
 }
 
+// End of the emitting kernel: the last block to finish (arrival counter counters[4]) writes the
+// overflow status and mirrors the final {count, overflow} pair to the caller's mirror (plain stores:
+// it may be pinned host memory).  out_count itself is only ever updated with device-scope atomics,
+// so the atomic read below sees every block's increments once all of them have arrived.
+__device__ __forceinline__ void publish_counts(int32_t* __restrict__ counters, int n_all, int cand_cap,
+                                               int32_t* __restrict__ out_count, int32_t* __restrict__ mirror_count)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int done = atomicAdd(&counters[4], 1);
+        if (done == (int)gridDim.x - 1) {
+            const int n_out = atomicAdd(out_count, 0);
+            const int flag = n_all > cand_cap ? 1 : 0;
+            out_count[1] = flag;
+            if (mirror_count) {
+                mirror_count[0] = n_out;
+                mirror_count[1] = flag;
+            }
+        }
+    }
+}
+
 // 16x16 patch of one candidate: lane = (row = lane>>2, 4 columns); the block's
 // LOCAL_WAVES waves each take a contiguous slice of the features and the partial
 // sums meet in LDS.  Result (packed u16) valid in wave 0.
@@ -945,13 +968,12 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
     const int32_t* __restrict__ raw_keep, const int32_t* __restrict__ class_idx,
     const int32_t* __restrict__ template_id, Cand* __restrict__ cands, int32_t* __restrict__ counters,
     int cand_cap, int is_last, sbm_match_rec* __restrict__ out, int32_t* __restrict__ out_count,
-    int out_cap)
+    int out_cap, sbm_match_rec* __restrict__ mirror_out, int32_t* __restrict__ mirror_count)
 {
     __shared__ uint32_t s_part[LOCAL_WAVES][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int n = counters[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && is_last) out_count[1] = n > cand_cap ? 1 : 0; // overflow status
-    n = n < cand_cap ? n : cand_cap;
+    const int n_all = counters[0];
+    const int n = n_all < cand_cap ? n_all : cand_cap;
     const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
     for (int ci = blockIdx.x; ci < n; ci += gridDim.x) {
         Cand c = cands[ci];
@@ -1005,6 +1027,7 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
                         m.class_idx = class_idx[c.t];
                         m.template_id = template_id[c.t];
                         out[idx] = m;
+                        if (mirror_out) mirror_out[idx] = m; // e.g. pinned host memory: no copy engine involved
                     }
                 }
             } else {
@@ -1015,6 +1038,7 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
             }
         }
     }
+    if (is_last) publish_counts(counters, n_all, cand_cap, out_count, mirror_count);
 }
 
 // stage entry point: one 16x16 patch
@@ -1036,16 +1060,17 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local_patch(con
 
 // single-level pyramids: coarse candidates are the final matches
 __global__ __launch_bounds__(256) void k_emit_coarse(const Cand* __restrict__ cands,
-                                                     const int32_t* __restrict__ counters, int cand_cap,
+                                                     int32_t* __restrict__ counters, int cand_cap,
                                                      const DevTL* __restrict__ tls, int L, int lc,
                                                      const int32_t* __restrict__ class_idx,
                                                      const int32_t* __restrict__ template_id,
                                                      sbm_match_rec* __restrict__ out,
-                                                     int32_t* __restrict__ out_count, int out_cap)
+                                                     int32_t* __restrict__ out_count, int out_cap,
+                                                     sbm_match_rec* __restrict__ mirror_out,
+                                                     int32_t* __restrict__ mirror_count)
 {
-    int n = counters[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0) out_count[1] = n > cand_cap ? 1 : 0;
-    n = n < cand_cap ? n : cand_cap;
+    const int n_all = counters[0];
+    const int n = n_all < cand_cap ? n_all : cand_cap;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const Cand c = cands[i];
         const DevTL tl = tls[(size_t)c.t * L + lc];
@@ -1059,8 +1084,10 @@ __global__ __launch_bounds__(256) void k_emit_coarse(const Cand* __restrict__ ca
             m.class_idx = class_idx[c.t];
             m.template_id = template_id[c.t];
             out[idx] = m;
+            if (mirror_out) mirror_out[idx] = m;
         }
     }
+    publish_counts(counters, n_all, cand_cap, out_count, mirror_count);
 }
 
 } // namespace sbm

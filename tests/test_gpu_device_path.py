@@ -1,0 +1,91 @@
+"""-m gpu: sbm_match_device (frame resident in HBM, caller's stream, caller's result buffers), in
+hipGraph mode and plain-stream mode, with and without the pinned-host result mirror."""
+import numpy as np
+import pytest
+
+from shape_based_matching_amd import synth
+from shape_based_matching_amd.templates import MATCH_DTYPE
+
+pytestmark = pytest.mark.gpu
+
+
+def key(recs):
+    return sorted(np.ascontiguousarray(recs, MATCH_DTYPE).tolist())
+
+
+def frame_of(case1):
+    img = case1["test"]
+    return synth.embed(img, 640, 768, 80, 80)
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_match_device_matches_oracle(oracle, ctx_factory, case1, graph):
+    import torch
+
+    dev = torch.device("cuda", 0)
+    ts = case1["templates"].subset(range(280, 361, 2))
+    frame = frame_of(case1)
+    ctx = ctx_factory()
+    ctx.set_graph_mode(graph)
+    ctx.upload_templates(ts)
+    cap = 2048
+    stream = torch.cuda.Stream(device=dev)
+    d_imgs = [torch.from_numpy(frame).to(dev), torch.from_numpy(np.ascontiguousarray(frame[:, ::-1])).to(dev)]
+    d_out = torch.zeros(cap * MATCH_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    h_out = torch.zeros(cap * MATCH_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
+    h_cnt = torch.zeros(2, dtype=torch.int32).pin_memory()
+    frames = [frame, np.ascontiguousarray(frame[:, ::-1])]
+    want = {}
+    for thr in (90.0, 75.0):
+        for i, fr in enumerate(frames):
+            pyr = oracle.Pyramid.build(fr, [4, 8], 30.0)
+            want[(thr, i)] = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr)
+    assert len(want[(90.0, 0)]) > 0
+    for mirror in (False, True):
+        ctx.set_result_mirror(h_out.data_ptr() if mirror else 0, h_cnt.data_ptr() if mirror else 0)
+        for rep in range(3):  # replays of the captured graphs, alternating frames and thresholds
+            for thr in (90.0, 75.0):
+                for i in range(2):
+                    h_cnt.zero_()
+                    with torch.cuda.stream(stream):
+                        ctx.match_device(d_imgs[i].data_ptr(), frame.shape[0], frame.shape[1], frame.shape[1] * 3, 3, thr,
+                                         d_out.data_ptr(), cap, d_cnt.data_ptr(), stream=stream.cuda_stream)
+                    stream.synchronize()
+                    cnt = d_cnt.cpu().numpy()
+                    assert cnt[1] == 0
+                    got = d_out.cpu().numpy().view(MATCH_DTYPE)[: cnt[0]]
+                    assert key(got) == key(want[(thr, i)]), (mirror, rep, thr, i)
+                    if mirror:
+                        hc = h_cnt.numpy()
+                        assert hc[0] == cnt[0] and hc[1] == 0
+                        assert key(h_out.numpy().view(MATCH_DTYPE)[: hc[0]]) == key(want[(thr, i)])
+
+
+def test_match_device_back_to_back_frames(oracle, ctx_factory, case1):
+    """many frames queued on one stream without host synchronisation in between"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    ts = case1["templates"].subset(range(300, 361, 3))
+    frame = frame_of(case1)
+    ctx = ctx_factory()
+    ctx.upload_templates(ts)
+    cap = 1024
+    stream = torch.cuda.Stream(device=dev)
+    d_img = torch.from_numpy(frame).to(dev)
+    outs = [torch.zeros(cap * MATCH_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(4)]
+    cnts = [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(4)]
+    with torch.cuda.stream(stream):
+        for it in range(40):
+            k = it % 4
+            ctx.match_device(d_img.data_ptr(), frame.shape[0], frame.shape[1], frame.shape[1] * 3, 3, 88.0,
+                             outs[k].data_ptr(), cap, cnts[k].data_ptr(), stream=stream.cuda_stream)
+    stream.synchronize()
+    pyr = oracle.Pyramid.build(frame, [4, 8], 30.0)
+    want = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 88.0)
+    assert len(want) > 0
+    for k in range(4):
+        c = cnts[k].cpu().numpy()
+        assert c[0] == len(want) and c[1] == 0
+        assert key(outs[k].cpu().numpy().view(MATCH_DTYPE)[: c[0]]) == key(want)
