@@ -127,6 +127,8 @@ def main():
             self.ctx = capi.Context(T=T_LEVELS, weak_threshold=30.0, device_id=local_rank)
             self.ctx.upload_templates(ts)
             self.ctx.select_range(first, count)
+            if os.environ.get("SBM_GRAPH"):
+                self.ctx.set_graph_mode(True)
             # always an explicit stream: handle 0 would mean "the context's own stream" to the C ABI and
             # the result copies below must be ordered after the kernels
             self.stream = torch.cuda.Stream(device=dev)

@@ -7,6 +7,7 @@
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -107,6 +108,7 @@ struct sbm_ctx {
     DevBuf d_img[SBM_MAX_LEVELS], d_mask[SBM_MAX_LEVELS], d_quant[SBM_MAX_LEVELS], d_lm[SBM_MAX_LEVELS];
     DevBuf d_geo; // T[L], W[L], H[L] as int32 then stride[L] as int64
     bool foff_dirty = true;
+    bool counters_fresh = false; // the linear-memory launch of this frame already reset the counters
 
     // candidates / results
     DevBuf d_cands, d_counters, d_out, d_outcount;
@@ -131,7 +133,7 @@ struct sbm_ctx {
     };
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
-    bool graph_mode = true;
+    bool graph_mode = false; // measured on ROCm 7.2 / MI355X: graph replay is slower than stream launches
     hipStream_t side = nullptr;
     hipEvent_t ev_fork[SBM_MAX_LEVELS] = {};
     hipEvent_t ev_join = nullptr;
@@ -287,17 +289,24 @@ int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, i
     return 0;
 }
 
+// the register-only linear-memory kernel handles the reference's strides on 16-byte aligned rows
+bool lm_rows_ok(const uint8_t* d_q, int cols, int T)
+{
+    return (T == 4 || T == 8) && ((cols / T) & 3) == 0 && (cols & 15) == 0 && (((uintptr_t)d_q) & 15) == 0;
+}
+
 int launch_build_lm(sbm_ctx* c, hipStream_t s, const uint8_t* d_q, int rows, int cols, int T, uint8_t* d_lm,
                     int64_t lm_stride)
 {
     const int W = cols / T, H = rows / T;
-    if ((T == 4 || T == 8) && (W & 3) == 0 && (cols & 15) == 0 && (((uintptr_t)d_q) & 15) == 0) {
+    if (lm_rows_ok(d_q, cols, T)) {
+        LmArgs a;
+        memset(&a, 0, sizeof a);
+        a.n_levels = 1;
+        a.lv[0] = LmLevelArgs{d_q, d_lm, lm_stride, rows, cols, W, H, T, 0};
         const int64_t items = (int64_t)rows * (W >> 2);
         Scope sc(c, s, "k_build_lm");
-        if (T == 4)
-            hipLaunchKernelGGL(k_build_lm_rows<4>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, d_q, rows, cols, W, H, d_lm, lm_stride);
-        else
-            hipLaunchKernelGGL(k_build_lm_rows<8>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, d_q, rows, cols, W, H, d_lm, lm_stride);
+        hipLaunchKernelGGL(k_build_lm_rows, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -383,12 +392,18 @@ int ensure_foff(sbm_ctx* c, hipStream_t s)
 }
 
 // gradient stage + linear memories for every level; d_img0 may be external
-int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride0, const uint8_t* d_mask0)
+// reset_count != null: the linear-memory launch also zeroes the per-frame counters and *reset_count
+// (c->counters_fresh tells enqueue_coarse to skip its own k_reset launch).
+int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride0, const uint8_t* d_mask0,
+                    int32_t* reset_count = nullptr)
 {
     const int ch = c->channels;
     const uint8_t* img = d_img0;
     int stride = stride0;
     const uint8_t* mask = d_mask0;
+    bool all_rows = true;
+    for (int l = 0; l < c->L; ++l) all_rows = all_rows && lm_rows_ok(c->d_quant[l].as<uint8_t>(), c->cols[l], c->cfg.T[l]);
+    c->counters_fresh = false;
     for (int l = 0; l < c->L; ++l) {
         if (l > 0) {
             const int pr = c->rows[l - 1], pc = c->cols[l - 1];
@@ -408,9 +423,29 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
                                     c->d_quant[l].as<uint8_t>(), nullptr, nullptr,
                                     l + 1 < c->L ? c->d_img[l + 1].as<uint8_t>() : nullptr))
             return e;
-        if (int e = launch_build_lm(c, s, c->d_quant[l].as<uint8_t>(), c->rows[l], c->cols[l], c->cfg.T[l],
-                                    c->d_lm[l].as<uint8_t>(), c->lm_stride[l]))
-            return e;
+        if (!all_rows)
+            if (int e = launch_build_lm(c, s, c->d_quant[l].as<uint8_t>(), c->rows[l], c->cols[l], c->cfg.T[l],
+                                        c->d_lm[l].as<uint8_t>(), c->lm_stride[l]))
+                return e;
+    }
+    if (all_rows) { // every level's linear memories (and the counter reset) in one launch
+        LmArgs a;
+        memset(&a, 0, sizeof a);
+        a.n_levels = c->L;
+        int blocks = 0;
+        for (int l = 0; l < c->L; ++l) {
+            const int T = c->cfg.T[l], W = c->cols[l] / T, H = c->rows[l] / T;
+            a.lv[l] = LmLevelArgs{c->d_quant[l].as<uint8_t>(), c->d_lm[l].as<uint8_t>(), c->lm_stride[l], c->rows[l], c->cols[l], W, H, T, blocks};
+            blocks += (int)(((int64_t)c->rows[l] * (W >> 2) + 255) / 256);
+        }
+        if (reset_count) {
+            a.counters = c->d_counters.as<int32_t>();
+            a.out_count = reset_count;
+            c->counters_fresh = true;
+        }
+        Scope sc(c, s, "k_build_lm");
+        hipLaunchKernelGGL(k_build_lm_rows, dim3(blocks), dim3(256), 0, s, a);
+        HIP_TRY(hipGetLastError());
     }
     c->levels_valid = c->L;
     return 0;
@@ -431,7 +466,8 @@ int enqueue_coarse(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap,
 {
     const int L = c->L, lc = L - 1;
     int32_t* counters = c->d_counters.as<int32_t>();
-    hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s, counters, d_count);
+    if (!c->counters_fresh) hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s, counters, d_count);
+    c->counters_fresh = false;
     const int n_active = (int)c->h_active.size();
     if (n_active > 0) {
         const int T = c->cfg.T[lc], W = c->cols[lc] / T, H = c->rows[lc] / T;
@@ -513,7 +549,8 @@ int capture_match_graph(sbm_ctx* c, const uint8_t* d_img0, int stride0, const ui
         rc = launch_quantize(c, m, img, c->rows[l], c->cols[l], stride, ch, mask, c->cfg.weak_threshold, c->d_quant[l].as<uint8_t>(),
                              nullptr, nullptr, l + 1 < L ? c->d_img[l + 1].as<uint8_t>() : nullptr);
         if (rc) break;
-        if (l < L - 1) {
+        static const bool use_fork = getenv("SBM_GRAPH_FORK") ? atoi(getenv("SBM_GRAPH_FORK")) != 0 : true;
+        if (l < L - 1 && use_fork) {
             if (hipEventRecord(c->ev_fork[l], m) != hipSuccess || hipStreamWaitEvent(sd, c->ev_fork[l], 0) != hipSuccess) {
                 rc = fail(SBM_ERR_HIP, "graph fork failed");
                 break;
@@ -753,18 +790,21 @@ int sbm_match_device(sbm_ctx* c, const void* d_img, int32_t rows, int32_t cols, 
     if (stride < cols * channels) return fail(SBM_ERR_INVALID, "stride %d < cols*channels", stride);
     HIP_TRY(hipSetDevice(c->cfg.device_id));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // anything the launches below are about to change may still be read by frames in flight
+    const bool dirty = !(c->channels == channels && c->rows[0] == rows && c->cols[0] == cols && c->levels_valid == c->L) ||
+                       !c->have_thr || memcmp(&threshold, &c->thr_cached, 4) != 0 || c->foff_dirty;
+    if (dirty) HIP_TRY(hipDeviceSynchronize());
     if (!c->graph_mode || c->profiling) {
         if (int e = ensure_geometry(c, rows, cols, channels)) return e;
         if (c->profiling) c->clear_timings();
-        if (int e = enqueue_pyramid(c, s, (const uint8_t*)d_img, stride, (const uint8_t*)d_mask)) return e;
-        return enqueue_templates(c, s, threshold, (sbm_match_rec*)d_out, cap, (int32_t*)d_count);
+        if (int e = prepare_templates(c, c->stream, threshold, cap)) return e;
+        if (int e = enqueue_pyramid(c, s, (const uint8_t*)d_img, stride, (const uint8_t*)d_mask, (int32_t*)d_count)) return e;
+        if (int e = enqueue_coarse(c, s, (sbm_match_rec*)d_out, cap, (int32_t*)d_count)) return e;
+        return enqueue_local(c, s, (sbm_match_rec*)d_out, cap, (int32_t*)d_count);
     }
     // graph path: all state changes happen up front (they may synchronise), then one hipGraphLaunch
     uint32_t thr_bits;
     memcpy(&thr_bits, &threshold, 4);
-    const bool dirty = !(c->channels == channels && c->rows[0] == rows && c->cols[0] == cols && c->levels_valid == c->L) ||
-                       !c->have_thr || memcmp(&threshold, &c->thr_cached, 4) != 0 || c->foff_dirty;
-    if (dirty) HIP_TRY(hipDeviceSynchronize()); // earlier launches may still read what is about to change
     if (int e = ensure_geometry(c, rows, cols, channels)) return e;
     if (int e = prepare_templates(c, c->stream, threshold, cap)) return e;
     sbm_ctx::GraphEntry* hit = nullptr;
@@ -830,8 +870,12 @@ int sbm_match(sbm_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_
     HIP_TRY(hipSetDevice(c->cfg.device_id));
     if (c->profiling) c->clear_timings();
     if (int e = upload_image(c, img, rows, cols, stride, channels, mask)) return e;
-    if (int e = enqueue_pyramid(c, c->stream, c->d_img[0].as<uint8_t>(), cols * channels, mask ? c->d_mask[0].as<uint8_t>() : nullptr)) return e;
-    if (int e = enqueue_templates(c, c->stream, threshold, c->d_out.as<sbm_match_rec>(), c->cand_cap, c->d_outcount.as<int32_t>())) return e;
+    if (int e = prepare_templates(c, c->stream, threshold, c->cand_cap)) return e;
+    if (int e = enqueue_pyramid(c, c->stream, c->d_img[0].as<uint8_t>(), cols * channels, mask ? c->d_mask[0].as<uint8_t>() : nullptr,
+                                c->d_outcount.as<int32_t>()))
+        return e;
+    if (int e = enqueue_coarse(c, c->stream, c->d_out.as<sbm_match_rec>(), c->cand_cap, c->d_outcount.as<int32_t>())) return e;
+    if (int e = enqueue_local(c, c->stream, c->d_out.as<sbm_match_rec>(), c->cand_cap, c->d_outcount.as<int32_t>())) return e;
     int rc = fetch_results(c, c->stream, out, cap, n_out);
     if (c->profiling) collect_timings(c);
     return rc;

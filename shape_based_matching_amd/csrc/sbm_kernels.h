@@ -202,6 +202,33 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t* __restrict__ im
         }
     }
 
+    // ---- flat-tile shortcut: if every channel of the source tile is constant, every gradient is 0,
+    //      no pixel passes `mag > weak^2` and the whole output tile is 0 (padding / saturated background:
+    //      the reference's own demo pads the frame with 250 black pixels, test.cpp:344-347).
+    //      WITH_FLOAT keeps the full path so that magnitude / angle are written everywhere. ----
+    if (!WITH_FLOAT && thr_sq >= 0.f) {
+        bool flat = true;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const uint32_t ref = (s_src[k][0][0] & 0xffu) * 0x01010101u;
+            for (int it = tid; it < QS_R * (QS_W / 4); it += 256) flat = flat && (s_src[k][it / (QS_W / 4)][it % (QS_W / 4)] == ref);
+        }
+        if (__syncthreads_and(flat)) {
+            const int er = tid >> 4, g = tid & 15;
+            const int r = R0 + er;
+            if (r < rows) {
+                uint8_t* o = out + (size_t)r * cols + C0 + 4 * g;
+                if (C0 + 4 * g + 3 < cols && ((((size_t)r * cols + C0 + 4 * g) & 3) == 0)) {
+                    *(uint32_t*)o = 0;
+                } else {
+                    for (int m = 0; m < 4; ++m)
+                        if (C0 + 4 * g + m < cols) o[m] = 0;
+                }
+            }
+            return;
+        }
+    }
+
     // ---- B: horizontal 7-tap: output x (image col C0-4+x) reads source bytes x+1 .. x+7 ----
     for (int it = tid; it < CH * QS_R * (QH_W / 4); it += 256) {
         const int k = it / (QS_R * (QH_W / 4)), rem = it - k * (QS_R * (QH_W / 4));
@@ -531,12 +558,11 @@ __device__ __forceinline__ uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t 
 }
 
 template <int T>
-__global__ __launch_bounds__(256) void k_build_lm_rows(const uint8_t* __restrict__ q, int rows, int cols, int W,
-                                                       int H, uint8_t* __restrict__ lm, int64_t lm_stride)
+__device__ __forceinline__ void build_lm_rows_item(const uint8_t* __restrict__ q, int rows, int cols, int W, int H,
+                                                   uint8_t* __restrict__ lm, int64_t lm_stride, int64_t item)
 {
     constexpr int NQ = T / 4 * 4; // dwords of own pixels per lane (4 cells * T px / 4)
     const int lanes_per_row = W >> 2;
-    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row_id = item / lanes_per_row; // = gy * T + ty  (a pixel row index)
     const int k = (int)(item - row_id * lanes_per_row);
     if (row_id >= rows) return;
@@ -597,6 +623,38 @@ __global__ __launch_bounds__(256) void k_build_lm_rows(const uint8_t* __restrict
 #pragma unroll
         for (int o = 0; o < 8; ++o) *(uint32_t*)(lm + o * lm_stride + dst) = response4(sp, o);
     }
+}
+
+// All pyramid levels in one launch: block ranges per level (levels whose T is 4 or 8), plus the
+// reset of the per-frame counters, so the whole linear-memory stage costs one kernel boundary.
+struct LmLevelArgs {
+    const uint8_t* q;
+    uint8_t* lm;
+    int64_t lm_stride;
+    int32_t rows, cols, W, H, T;
+    int32_t block_begin; // first block of this level
+};
+struct LmArgs {
+    LmLevelArgs lv[SBM_MAX_LEVELS];
+    int32_t n_levels;
+    int32_t* counters;  // may be null
+    int32_t* out_count; // may be null
+};
+
+__global__ __launch_bounds__(256) void k_build_lm_rows(const LmArgs a)
+{
+    if (blockIdx.x == 0 && a.counters) {
+        if (threadIdx.x < 8) a.counters[threadIdx.x] = 0;
+        if (threadIdx.x < 2 && a.out_count) a.out_count[threadIdx.x] = 0;
+    }
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < SBM_MAX_LEVELS; ++i)
+        if (i < a.n_levels && (int)blockIdx.x >= a.lv[i].block_begin) l = i;
+    const LmLevelArgs& p = a.lv[l];
+    const int64_t item = (int64_t)((int)blockIdx.x - p.block_begin) * 256 + threadIdx.x;
+    if (p.T == 4) build_lm_rows_item<4>(p.q, p.rows, p.cols, p.W, p.H, p.lm, p.lm_stride, item);
+    else build_lm_rows_item<8>(p.q, p.rows, p.cols, p.W, p.H, p.lm, p.lm_stride, item);
 }
 
 // unfused single-function kernels (stage entry points / parity tests)
