@@ -281,7 +281,7 @@ struct sbo_pyramid {
 static int64_t lm_stride_for(int rows, int cols, int T)
 {
     int64_t W = cols / T, H = rows / T;
-    int64_t s = (int64_t)T * T * W * H + W * H + 16 * W + 16;
+    int64_t s = (int64_t)T * T * W * H + W * H + 16 * W + 80;
     return (s + 63) / 64 * 64;
 }
 

@@ -77,7 +77,7 @@ struct Timing {
 int64_t lm_stride_for(int rows, int cols, int T)
 {
     int64_t W = cols / T, H = rows / T;
-    int64_t s = (int64_t)T * T * W * H + W * H + 16 * W + 16;
+    int64_t s = (int64_t)T * T * W * H + W * H + 16 * W + 80;
     return (s + 63) / 64 * 64;
 }
 
@@ -278,13 +278,13 @@ int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, i
     const bool wf = d_mag || d_ori;
     Scope sc(c, s, "k_quantize");
     if (ch == 1 && !wf)
-        hipLaunchKernelGGL((k_quantize<1, false>), grid, dim3(256), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
+        hipLaunchKernelGGL((k_quantize<1, false>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
     else if (ch == 1)
-        hipLaunchKernelGGL((k_quantize<1, true>), grid, dim3(256), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
+        hipLaunchKernelGGL((k_quantize<1, true>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
     else if (!wf)
-        hipLaunchKernelGGL((k_quantize<3, false>), grid, dim3(256), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
+        hipLaunchKernelGGL((k_quantize<3, false>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
     else
-        hipLaunchKernelGGL((k_quantize<3, true>), grid, dim3(256), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
+        hipLaunchKernelGGL((k_quantize<3, true>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -98,6 +98,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 //      orientation bins, 'strong' flag (mag > weak^2).
 //   E  3x3 majority vote (>= 5 of 9) around strong pixels -> one-hot byte.
 // ---------------------------------------------------------------------------
+constexpr int QN = 1024; // threads per tile: short per-wave instruction streams, 16 waves hide each other's latency
 constexpr int QS_W = 80; // source tile width  (cols C0-8 .. C0+71)
 constexpr int QH_W = 72; // h / smoothed / q tile width (cols C0-4 .. C0+67)
 
@@ -108,7 +109,7 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
 }
 
 template <int CH, bool WITH_FLOAT>
-__global__ __launch_bounds__(256) void k_quantize(const uint8_t* __restrict__ img, int rows, int cols,
+__global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img, int rows, int cols,
                                                   int stride, const uint8_t* __restrict__ mask,
                                                   float thr_sq, uint8_t* __restrict__ out,
                                                   float* __restrict__ mag_out, float* __restrict__ ori_out,
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t* __restrict__ im
 
     // ---- A: source tile -> planar LDS (rows clamped; a 4-pixel group that sticks out of the image
     //         left or right takes the per-byte clamped path = BORDER_REPLICATE) ----
-    for (int it = tid; it < QS_R * (QS_W / 4); it += 256) {
+    for (int it = tid; it < QS_R * (QS_W / 4); it += QN) {
         const int r = it / (QS_W / 4), g = it - r * (QS_W / 4);
         const int gr = clampi(R0 - 5 + r, 0, rows - 1);
         const int c = C0 - 8 + 4 * g;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t* __restrict__ im
     __syncthreads();
 
     // ---- P: pyrDown of this tile (8 x 32 outputs), REFLECT_101 at the image border ----
-    if (pyr_out) {
+    if (pyr_out && tid < 256) {
         const int yy = tid >> 5, xx = tid & 31;
         const int oy = (R0 >> 1) + yy, ox = (C0 >> 1) + xx;
         const int drows = rows >> 1, dcols = cols >> 1;
@@ -211,12 +212,12 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t* __restrict__ im
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             const uint32_t ref = (s_src[k][0][0] & 0xffu) * 0x01010101u;
-            for (int it = tid; it < QS_R * (QS_W / 4); it += 256) flat = flat && (s_src[k][it / (QS_W / 4)][it % (QS_W / 4)] == ref);
+            for (int it = tid; it < QS_R * (QS_W / 4); it += QN) flat = flat && (s_src[k][it / (QS_W / 4)][it % (QS_W / 4)] == ref);
         }
         if (__syncthreads_and(flat)) {
             const int er = tid >> 4, g = tid & 15;
             const int r = R0 + er;
-            if (r < rows) {
+            if (tid < 256 && r < rows) {
                 uint8_t* o = out + (size_t)r * cols + C0 + 4 * g;
                 if (C0 + 4 * g + 3 < cols && ((((size_t)r * cols + C0 + 4 * g) & 3) == 0)) {
                     *(uint32_t*)o = 0;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t* __restrict__ im
     }
 
     // ---- B: horizontal 7-tap: output x (image col C0-4+x) reads source bytes x+1 .. x+7 ----
-    for (int it = tid; it < CH * QS_R * (QH_W / 4); it += 256) {
+    for (int it = tid; it < CH * QS_R * (QH_W / 4); it += QN) {
         const int k = it / (QS_R * (QH_W / 4)), rem = it - k * (QS_R * (QH_W / 4));
         const int r = rem / (QH_W / 4), g = rem - r * (QH_W / 4);
         const uint32_t d0 = s_src[k][r][g], d1 = s_src[k][r][g + 1], d2 = s_src[k][r][g + 2];
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t* __restrict__ im
     __syncthreads();
 
     // ---- C: vertical 7-tap over s_h rows jr .. jr+6, two pixels (one dword column) per item ----
-    for (int it = tid; it < CH * QM_R * (QH_W / 2); it += 256) {
+    for (int it = tid; it < CH * QM_R * (QH_W / 2); it += QN) {
         const int k = it / (QM_R * (QH_W / 2)), rem = it - k * (QM_R * (QH_W / 2));
         const int jr = rem / (QH_W / 2), d = rem - jr * (QH_W / 2);
         uint32_t a[7];
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t* __restrict__ im
     __syncthreads();
     if (!interior) { // replicate the smoothed image outwards: Sobel runs with BORDER_REPLICATE
         uint8_t* sm = (uint8_t*)&s_sm[0][0][0];
-        for (int it = tid; it < CH * QM_R * QH_W; it += 256) {
+        for (int it = tid; it < CH * QM_R * QH_W; it += QN) {
             const int k = it / (QM_R * QH_W), rem = it - k * (QM_R * QH_W);
             const int jr = rem / QH_W, x = rem - jr * QH_W;
             const int r = R0 - 2 + jr, c = C0 - 4 + x;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t* __restrict__ im
     }
 
     // ---- D: Sobel + magnitude + orientation bin; q row qr <-> image row R0-1+qr <-> s_sm row qr+1 ----
-    for (int it = tid; it < QQ_R * (QH_W / 4); it += 256) {
+    for (int it = tid; it < QQ_R * (QH_W / 4); it += QN) {
         const int qr = it / (QH_W / 4), g = it - qr * (QH_W / 4);
         const int gm = g > 0 ? g - 1 : 0, gp = g < QH_W / 4 - 1 ? g + 1 : g;
         int bx[4] = {0, 0, 0, 0}, by[4] = {0, 0, 0, 0}, bm[4] = {-1, -1, -1, -1};
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void k_quantize(const uint8_t* __restrict__ im
     __syncthreads();
 
     // ---- E: 3x3 majority vote (>= 5 of 9); out cols C0+4g .. +3 <-> q columns 4(g+1) .. +3 ----
-    {
+    if (tid < 256) {
         const int er = tid >> 4, g = tid & 15;
         const int r = R0 + er;
         if (r < rows) {
@@ -727,6 +728,7 @@ __device__ __forceinline__ int template_positions(const DevTL& tl, int W, int H,
 
 constexpr int SIM_POS_PER_BLOCK = 1024; // 256 lanes x 4 positions
 constexpr int FB = 8;                   // features per batch: FB independent loads in flight per lane
+constexpr int FB16 = 8;                 // same for the 16-byte variant (coarse pass)
 
 // Sum `count` features starting at `f0` into packed 16-bit lanes.  Each lane
 // owns 4 consecutive bytes at lm + foff[f] + lane_off.  The wave first loads 64
@@ -807,7 +809,7 @@ __device__ __forceinline__ int unpack4(uint32_t lo, uint32_t hi, int k)
 __device__ __forceinline__ void accumulate_features16(const uint8_t* __restrict__ lm,
                                                       const uint32_t* __restrict__ fxy,
                                                       const int32_t* __restrict__ foff, int count,
-                                                      int rows, int cols, int j0, int zero_off,
+                                                      int rows, int cols, int j0, bool lane_on, int zero_off,
                                                       uint32_t (&lo)[4], uint32_t (&hi)[4])
 {
     const int lane = threadIdx.x & 63;
@@ -818,35 +820,49 @@ __device__ __forceinline__ void accumulate_features16(const uint8_t* __restrict_
     int pending = 0;
     count = __builtin_amdgcn_readfirstlane(count); // wave-uniform by contract: keep the loop control scalar
     for (int b = 0; b < count; b += 64) {
-        int sel = zero_off;
+        int sel = zero_off; // computed with every lane active: v_readlane below reads any lane's copy
         if (b + lane < count) {
             const uint32_t xy = fxy[b + lane];
             const int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
             if (x < cols && y < rows) sel = foff[b + lane];
         }
         const int nb = count - b < 64 ? count - b : 64;
+        // lanes past the template's span (lane_on == false) issue no loads at all; lane 63 fetches the
+        // 4 bytes that follow its 16, every other lane takes them from its right neighbour's load (DPP)
         auto batch = [&](auto N, int u) {
             constexpr int n = decltype(N)::value;
             u128_a4 q[n];
             uint32_t e[n];
             int sh[n];
+            if (lane_on) {
 #pragma unroll
-            for (int k = 0; k < n; ++k) {
-                const int o = __builtin_amdgcn_readlane(sel, (u + k) & 63);
-                sh[k] = o & 3;
-                const uint8_t* a = p + (o & ~3);
-                q[k] = *(const u128_a4*)a;
-                e[k] = *(const uint32_t*)(a + 16);
+                for (int k = 0; k < n; ++k) {
+                    const int o = __builtin_amdgcn_readlane(sel, (u + k) & 63);
+                    sh[k] = o & 3;
+                    const uint8_t* a = p + (o & ~3);
+                    q[k] = *(const u128_a4*)a;
+                    e[k] = 0;
+                    if (lane == 63) e[k] = *(const uint32_t*)(a + 16);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < n; ++k) {
+                    q[k] = u128_a4{0, 0, 0, 0};
+                    e[k] = 0;
+                    sh[k] = 0;
+                }
             }
 #pragma unroll
             for (int k = 0; k < n; ++k) {
+                // wave_shl:1 -> lane i receives lane i+1's first dword; lane 63 keeps its own loaded value
+                const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)e[k], (int)q[k].x, 0x130, 0xf, 0xf, false);
                 acc[0] += __builtin_amdgcn_alignbyte(q[k].y, q[k].x, sh[k]);
                 acc[1] += __builtin_amdgcn_alignbyte(q[k].z, q[k].y, sh[k]);
                 acc[2] += __builtin_amdgcn_alignbyte(q[k].w, q[k].z, sh[k]);
-                acc[3] += __builtin_amdgcn_alignbyte(e[k], q[k].w, sh[k]);
+                acc[3] += __builtin_amdgcn_alignbyte(nx, q[k].w, sh[k]);
             }
             pending += n;
-            if (pending + FB > 63) {
+            if (pending + FB16 > 63) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     lo[i] += acc[i] & 0x00ff00ffu;
@@ -857,7 +873,7 @@ __device__ __forceinline__ void accumulate_features16(const uint8_t* __restrict_
             }
         };
         int u = 0;
-        for (; u + FB <= nb; u += FB) batch(std::integral_constant<int, FB>{}, u);
+        for (; u + FB16 <= nb; u += FB16) batch(std::integral_constant<int, FB16>{}, u);
         if (nb - u >= 4) { batch(std::integral_constant<int, 4>{}, u); u += 4; }
         if (nb - u >= 2) { batch(std::integral_constant<int, 2>{}, u); u += 2; }
         if (nb - u >= 1) batch(std::integral_constant<int, 1>{}, u);
@@ -903,12 +919,15 @@ __global__ __launch_bounds__(256) void k_similarity_coarse(
     uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
     if (base < npos) { // block-uniform: every lane takes part (features are spread over the wave's lanes)
         const int zero_off = (int)(7 * lm_stride + (int64_t)T * T * W * H); // zero tail of the last orientation
-        const int jl = j0 < npos ? j0 : 0; // lanes past the span load valid bytes and discard them
+        // lanes past the span take no part in the loads (one extra lane does: its first dword is its
+        // left neighbour's bytes 16..19)
+        const bool lane_on = j0 < npos + 16;
         const int chunk = (tl.nf + 3) >> 2;
         const int f0 = wave * chunk;
         int cnt = tl.nf - f0;
         cnt = cnt < 0 ? 0 : (cnt > chunk ? chunk : cnt);
-        accumulate_features16(lm, fxy + tl.feat_off + f0, foff + tl.feat_off + f0, cnt, rows, cols, jl, zero_off, lo, hi);
+        accumulate_features16(lm, fxy + tl.feat_off + f0, foff + tl.feat_off + f0, cnt, rows, cols, lane_on ? j0 : 0, lane_on,
+                              zero_off, lo, hi);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

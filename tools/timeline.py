@@ -3,7 +3,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', '')[:40]) for r in rows]
-if len(sys.argv) > 2:
+if len(sys.argv) > 2 and sys.argv[2]:
     for r in csv.DictReader(open(sys.argv[2])):
         ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'COPY ' + r.get('Direction', '')))
 ev.sort()
