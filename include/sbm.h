@@ -187,7 +187,9 @@ int sbm_coarse_bytes(sbm_ctx* ctx, int64_t* bytes);
 
 /* Counters of the last template-matching call: coarse candidates found
  * (line2Dup.cpp:1208-1214) and the algorithmic bytes of the refinement passes,
- * sum over refined candidates of nf_level * 256.  Synchronises. */
+ * sum over refined candidates of nf_level * 256 (accumulated only
+ * while profiling is enabled, to keep the atomic out of the throughput path).
+ * Synchronises. */
 int sbm_get_stats(sbm_ctx* ctx, int64_t* n_candidates, int64_t* refine_bytes);
 
 #ifdef __cplusplus

@@ -478,6 +478,7 @@ int enqueue_coarse(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap,
             hipLaunchKernelGGL(k_similarity_coarse, dim3(chunks, cnt), dim3(256), 0, s, c->d_lm[lc].as<uint8_t>(),
                                c->lm_stride[lc], c->rows[lc], c->cols[lc], T, W, H, L, lc, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(),
                                c->d_foff.as<int32_t>(), c->d_active.as<int32_t>() + first, c->d_rawmin.as<int32_t>(),
+                               c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
                                c->d_cands.as<Cand>(), counters, (int)c->cand_cap);
         }
         HIP_TRY(hipGetLastError());
@@ -500,11 +501,11 @@ int enqueue_local(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap, 
     for (int l = L - 2; l >= 0; --l) {
         const int T = c->cfg.T[l], W = c->cols[l] / T, H = c->rows[l] / T;
         Scope sc(c, s, "k_similarity_local");
-        hipLaunchKernelGGL(k_similarity_local, dim3(256), dim3(64 * LOCAL_WAVES), 0, s, c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
+        hipLaunchKernelGGL(k_similarity_local, dim3(512), dim3(64 * LOCAL_WAVES), 0, s, c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
                            c->rows[l], c->cols[l], T, W, H, L, l, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(), c->d_foff.as<int32_t>(),
                            c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
                            c->d_cands.as<Cand>(), counters, (int)c->cand_cap, l == 0 ? 1 : 0, d_out, d_count, (int)cap,
-                           c->mirror_out, c->mirror_count);
+                           c->mirror_out, c->mirror_count, c->profiling ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
     return 0;

@@ -26,12 +26,37 @@ struct DevTL {
     int32_t width, height, nf, feat_off;
 };
 // coarse candidate / refinement state (Match under construction)
+// Carries everything the NEXT refinement pass needs (the template record of that level, its keep
+// threshold, the ids of the final Match), so that pass starts its feature loads after one
+// dependent read instead of three.
 struct Cand {
     int32_t t;   // template index (into the uploaded list)
     int32_t x;   // Match::x at the level just processed
     int32_t y;
     int32_t raw; // integer similarity sum; < 0 = dropped by the per-level filter
+    int32_t next_width, next_height, next_nf, next_feat_off; // DevTL of the level refined next
+    int32_t next_keep;                                       // raw_keep of that level
+    int32_t class_idx, template_id;
+    int32_t pad;
 };
+static_assert(sizeof(Cand) == 48, "Cand layout");
+
+__device__ __forceinline__ void cand_fill_next(Cand& c, const DevTL* __restrict__ tls, const int32_t* __restrict__ raw_keep,
+                                               const int32_t* __restrict__ class_idx, const int32_t* __restrict__ template_id,
+                                               int L, int next_level)
+{
+    if (next_level >= 0) {
+        const DevTL tn = tls[(size_t)c.t * L + next_level];
+        c.next_width = tn.width;
+        c.next_height = tn.height;
+        c.next_nf = tn.nf;
+        c.next_feat_off = tn.feat_off;
+        c.next_keep = raw_keep[(size_t)c.t * L + next_level];
+    }
+    c.class_idx = class_idx[c.t];
+    c.template_id = template_id[c.t];
+    c.pad = 0;
+}
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int reflect101(int p, int len)
@@ -902,7 +927,8 @@ constexpr int COARSE_POS_PER_BLOCK = 1024;
 __global__ __launch_bounds__(256) void k_similarity_coarse(
     const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int lc,
     const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
-    const int32_t* __restrict__ active, const int32_t* __restrict__ raw_min, Cand* __restrict__ cands,
+    const int32_t* __restrict__ active, const int32_t* __restrict__ raw_min, const int32_t* __restrict__ raw_keep,
+    const int32_t* __restrict__ class_idx, const int32_t* __restrict__ template_id, Cand* __restrict__ cands,
     int32_t* __restrict__ counters, int cap)
 {
     __shared__ uint32_t s_red[4][8][64];
@@ -952,6 +978,7 @@ __global__ __launch_bounds__(256) void k_similarity_coarse(
                 c.x = (j % W) * T + offset;
                 c.y = (j / W) * T + offset;
                 c.raw = raw;
+                cand_fill_next(c, tls, raw_keep, class_idx, template_id, L, lc - 1);
                 cands[idx] = c;
             }
         }
@@ -982,18 +1009,25 @@ __global__ __launch_bounds__(256) void k_similarity_map(const uint8_t* __restric
     }
 }
 
-// End of the emitting kernel: the last block to finish (arrival counter counters[4]) writes the
+// End of the emitting kernel: the last WORKING block to finish (arrival counter counters[4]) writes the
 // overflow status and mirrors the final {count, overflow} pair to the caller's mirror (plain stores:
-// it may be pinned host memory).  out_count itself is only ever updated with device-scope atomics,
-// so the atomic read below sees every block's increments once all of them have arrived.
-__device__ __forceinline__ void publish_counts(int32_t* __restrict__ counters, int n_all, int cand_cap,
-                                               int32_t* __restrict__ out_count, int32_t* __restrict__ mirror_count)
+// it may be pinned host memory).  Only blocks that had a candidate arrive — atomics on one address
+// serialise at ~25 ns each, so idle blocks must not queue up behind them; with no candidate at all
+// block 0 publishes.  out_count itself is only ever updated with device-scope atomics, so the atomic
+// read below sees every block's increments once all of them have arrived.
+__device__ __forceinline__ void publish_counts(int32_t* __restrict__ counters, int n_all, int n_work_blocks, bool worked,
+                                               int cand_cap, int32_t* __restrict__ out_count,
+                                               int32_t* __restrict__ mirror_count)
 {
+    if (!worked && !(n_work_blocks == 0 && blockIdx.x == 0)) return; // block-uniform
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
-        const int done = atomicAdd(&counters[4], 1);
-        if (done == (int)gridDim.x - 1) {
+        bool last = n_work_blocks == 0;
+        if (!last) {
+            __threadfence();
+            last = atomicAdd(&counters[4], 1) == n_work_blocks - 1;
+        }
+        if (last) {
             const int n_out = atomicAdd(out_count, 0);
             const int flag = n_all > cand_cap ? 1 : 0;
             out_count[1] = flag;
@@ -1045,17 +1079,24 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
     const int32_t* __restrict__ raw_keep, const int32_t* __restrict__ class_idx,
     const int32_t* __restrict__ template_id, Cand* __restrict__ cands, int32_t* __restrict__ counters,
     int cand_cap, int is_last, sbm_match_rec* __restrict__ out, int32_t* __restrict__ out_count,
-    int out_cap, sbm_match_rec* __restrict__ mirror_out, int32_t* __restrict__ mirror_count)
+    int out_cap, sbm_match_rec* __restrict__ mirror_out, int32_t* __restrict__ mirror_count, int collect_stats)
 {
     __shared__ uint32_t s_part[LOCAL_WAVES][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the candidate count and this block's first candidate are fetched together (the record is read
+    // speculatively: the buffer always exists, the count decides whether it is used)
+    Cand c = cands[blockIdx.x < (unsigned)cand_cap ? blockIdx.x : 0];
     const int n_all = counters[0];
     const int n = n_all < cand_cap ? n_all : cand_cap;
     const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
     for (int ci = blockIdx.x; ci < n; ci += gridDim.x) {
-        Cand c = cands[ci];
+        if (ci != (int)blockIdx.x) c = cands[ci];
         if (c.raw < 0) continue; // dropped at a coarser level (uniform per block)
-        const DevTL tl = tls[(size_t)c.t * L + l];
+        DevTL tl;
+        tl.width = c.next_width;
+        tl.height = c.next_height;
+        tl.nf = c.next_nf;
+        tl.feat_off = c.next_feat_off;
         int x = c.x * 2 + 1, y = c.y * 2 + 1;
         const int max_x = cols - tl.width - border, max_y = rows - tl.height - border;
         x = x < border ? border : x;
@@ -1081,7 +1122,7 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
             best = o > best ? o : best;
         }
         if (lane == 0) {
-            atomicAdd((unsigned long long*)(counters + 2), (unsigned long long)tl.nf * 256ull); // refinement bytes (stats)
+            if (collect_stats) atomicAdd((unsigned long long*)(counters + 2), (unsigned long long)tl.nf * 256ull); // refinement bytes
             const int raw = (int)(best >> 8);
             int br = -1, bc = -1;
             if (raw > 0) {
@@ -1091,7 +1132,7 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
             }
             const int nx = (x / T - 8 + bc) * T + offset;
             const int ny = (y / T - 8 + br) * T + offset;
-            const bool keep = raw >= raw_keep[(size_t)c.t * L + l];
+            const bool keep = raw >= c.next_keep;
             if (is_last) {
                 if (keep) {
                     int idx = atomicAdd(out_count, 1);
@@ -1101,8 +1142,8 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
                         m.y = ny;
                         m.similarity = __fdiv_rn(__fmul_rn((float)raw, 100.f), (float)(4 * tl.nf));
                         m.raw = raw;
-                        m.class_idx = class_idx[c.t];
-                        m.template_id = template_id[c.t];
+                        m.class_idx = c.class_idx;
+                        m.template_id = c.template_id;
                         out[idx] = m;
                         if (mirror_out) mirror_out[idx] = m; // e.g. pinned host memory: no copy engine involved
                     }
@@ -1111,11 +1152,15 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
                 c.x = nx;
                 c.y = ny;
                 c.raw = keep ? raw : -1;
+                if (keep) cand_fill_next(c, tls, raw_keep, class_idx, template_id, L, l - 1);
                 cands[ci] = c;
             }
         }
     }
-    if (is_last) publish_counts(counters, n_all, cand_cap, out_count, mirror_count);
+    if (is_last) {
+        const int n_work = n < (int)gridDim.x ? n : (int)gridDim.x;
+        publish_counts(counters, n_all, n_work, (int)blockIdx.x < n, cand_cap, out_count, mirror_count);
+    }
 }
 
 // stage entry point: one 16x16 patch
@@ -1164,7 +1209,12 @@ __global__ __launch_bounds__(256) void k_emit_coarse(const Cand* __restrict__ ca
             if (mirror_out) mirror_out[idx] = m;
         }
     }
-    publish_counts(counters, n_all, cand_cap, out_count, mirror_count);
+    {
+        const int per = (int)gridDim.x * 256;
+        const int n_work = (n + 255) / 256 < (int)gridDim.x ? (n + 255) / 256 : (int)gridDim.x;
+        (void)per;
+        publish_counts(counters, n_all, n_work, (int)blockIdx.x < n_work, cand_cap, out_count, mirror_count);
+    }
 }
 
 } // namespace sbm
