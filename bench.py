@@ -92,8 +92,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="frames in flight per GPU: independent contexts + streams used round-robin")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="frames in flight per GPU: independent engine contexts + HIP streams used round-robin "
+                         "(1 = strictly one frame at a time; the single-stream figure is always reported too)")
     args = ap.parse_args()
 
     import torch
@@ -182,6 +183,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # one frame at a time on one stream (latency-bound figure), same K steps, outside the timed region
+    single_ms = None
+    if len(slots) > 1:
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            slots[0].run()
+        fence()
+        single_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    else:
+        single_ms = elapsed / args.steps * 1e3
+
     # every slot must hold the same, stable match list (checked outside the timed region)
     ref_counts = None
     for rep in range(3):
@@ -220,9 +233,9 @@ def main():
         # algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md), by kernel
         npx = [(ROWS >> l) * (COLS >> l) for l in range(len(T_LEVELS))]
         alg = {
-            "k_quantize": [npx[0] * (3 + 1), npx[1] * (3 + 1)],
-            "k_build_lm": [npx[0] * 9, npx[1] * 9],
-            "k_pyrdown": [npx[0] * 3 + npx[1] * 3],
+            # frame read + one-hot map written (+ the next level's image, written by the fused pyrDown)
+            "k_quantize": [npx[0] * (3 + 1) + npx[1] * 3, npx[1] * (3 + 1)],
+            "k_build_lm": [sum(n * 9 for n in npx)],
             "k_similarity_coarse": [coarse_bytes],
             "k_similarity_local": [refine_bytes],
         }
@@ -232,6 +245,9 @@ def main():
             a = np.asarray(v).reshape(prof_steps, launches)
             kern[name] = {"ms_per_step": float(a.sum(axis=1).mean()), "launches": launches,
                           "avg_launch_us": float(a.mean() * 1e3)}
+            if name in alg:
+                kern[name]["algorithmic_bytes_per_step"] = float(sum(alg[name]))
+                kern[name]["achieved_GBps"] = float(sum(alg[name])) / (kern[name]["ms_per_step"] * 1e-3) / 1e9
         dom = max((k for k in kern if k in alg), key=lambda k: kern[k]["ms_per_step"])
         dom_bytes = float(sum(alg[dom])) / kern[dom]["launches"]
         dom_s = kern[dom]["avg_launch_us"] * 1e-6
@@ -243,6 +259,7 @@ def main():
                 traffic = json.load(open(pmc)).get(dom)
             except Exception:
                 traffic = None
+        step_bytes = float(sum(sum(v) for v in alg.values()))
         total_templates = ts.n_templates
         value = total_templates * (ROWS * COLS / 1e6) * args.steps / elapsed
         out = {
@@ -267,6 +284,7 @@ def main():
                 "frame": [ROWS, COLS, 3],
                 "parallelism": f"template-shard x{world}" + (" + RCCL all-gather of match lists" if world > 1 else ""),
                 "frames_in_flight": len(slots),
+                "ms_per_step_one_frame_at_a_time": single_ms,
                 "matches_distinct": n_matches,
                 "coarse_candidates_rank0": n_cand,
             },
@@ -280,6 +298,12 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": dom_bytes,
                 "avg_launch_us": kern[dom]["avg_launch_us"],
+                "note": "every kernel of a 1-Mpixel frame moves <= 10 MB from HBM (<= 1.3 us at 8 TB/s) and sits on "
+                        "the ~2.5 us launch floor; k_quantize is VALU-bound, k_similarity_coarse streams its 72 MB of "
+                        "algorithmic bytes from the L2-resident linear memories",
+                "whole_step": {"algorithmic_bytes": step_bytes,
+                               "achieved": step_bytes / (elapsed / args.steps) / 1e9,
+                               "frac": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
             },
             "kernels": kern,
         }

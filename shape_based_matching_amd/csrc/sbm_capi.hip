@@ -2,6 +2,7 @@
 // of the kernels in sbm_kernels.h.  gfx950 only; there is no CPU fallback: every
 // entry point fails with SBM_ERR_HIP when no GPU is usable.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <climits>
@@ -72,6 +73,7 @@ struct DevBuf {
 struct Timing {
     const char* name;
     hipEvent_t a, b;
+    bool shared_a = false; // a is the previous entry's b
 };
 
 int64_t lm_stride_for(int rows, int cols, int T)
@@ -151,14 +153,18 @@ struct sbm_ctx {
     std::vector<Timing> timings;
     std::vector<float> timing_ms;
 
+    hipEvent_t chain_event = nullptr;
+    hipStream_t chain_stream = nullptr;
     void clear_timings()
     {
         for (auto& t : timings) {
-            (void)hipEventDestroy(t.a);
+            if (!t.shared_a) (void)hipEventDestroy(t.a);
             (void)hipEventDestroy(t.b);
         }
         timings.clear();
         timing_ms.clear();
+        chain_event = nullptr;
+        chain_stream = nullptr;
     }
 };
 
@@ -173,17 +179,43 @@ struct Scope { // optional per-kernel HIP-event bracket on the launch stream
     {
         if (!on) return;
         t.name = name;
-        (void)hipEventCreate(&t.a);
+        // consecutive launches share one event: the end of the previous kernel is the start of this
+        // one, so a single event packet sits between two kernels (as in an un-instrumented stream)
+        if (c->chain_event && c->chain_stream == s) {
+            t.a = c->chain_event;
+            t.shared_a = true;
+        } else {
+            (void)hipEventCreate(&t.a);
+            (void)hipEventRecord(t.a, s);
+        }
         (void)hipEventCreate(&t.b);
-        (void)hipEventRecord(t.a, s);
     }
     ~Scope()
     {
         if (!on) return;
         (void)hipEventRecord(t.b, s);
+        c->chain_event = t.b;
+        c->chain_stream = s;
         c->timings.push_back(t);
     }
 };
+
+// Launch with exact kernel begin/end timestamps when profiling: hipExtLaunchKernelGGL stamps the
+// dispatch packet itself (what rocprofv3's kernel trace reads), so no event packet sits between
+// kernels and the measured durations are the kernels' own.
+#define SBM_LAUNCH(ctx, name_, kernel, grid, block, smem, stream, ...)                                        \
+    do {                                                                                                      \
+        if ((ctx)->profiling) {                                                                               \
+            Timing t_;                                                                                        \
+            t_.name = name_;                                                                                  \
+            (void)hipEventCreate(&t_.a);                                                                      \
+            (void)hipEventCreate(&t_.b);                                                                      \
+            hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, t_.a, t_.b, 0, __VA_ARGS__);             \
+            (ctx)->timings.push_back(t_);                                                                     \
+        } else {                                                                                              \
+            hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                               \
+        }                                                                                                     \
+    } while (0)
 
 int check_level_dims(int rows, int cols, int T)
 {
@@ -276,15 +308,14 @@ int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, i
     dim3 grid((cols + QT_C - 1) / QT_C, (rows + QT_R - 1) / QT_R);
     const float thr_sq = weak * weak;
     const bool wf = d_mag || d_ori;
-    Scope sc(c, s, "k_quantize");
     if (ch == 1 && !wf)
-        hipLaunchKernelGGL((k_quantize<1, false>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
+        SBM_LAUNCH(c, "k_quantize", (k_quantize<1, false>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
     else if (ch == 1)
-        hipLaunchKernelGGL((k_quantize<1, true>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
+        SBM_LAUNCH(c, "k_quantize", (k_quantize<1, true>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
     else if (!wf)
-        hipLaunchKernelGGL((k_quantize<3, false>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
+        SBM_LAUNCH(c, "k_quantize", (k_quantize<3, false>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
     else
-        hipLaunchKernelGGL((k_quantize<3, true>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
+        SBM_LAUNCH(c, "k_quantize", (k_quantize<3, true>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -305,8 +336,7 @@ int launch_build_lm(sbm_ctx* c, hipStream_t s, const uint8_t* d_q, int rows, int
         a.n_levels = 1;
         a.lv[0] = LmLevelArgs{d_q, d_lm, lm_stride, rows, cols, W, H, T, 0};
         const int64_t items = (int64_t)rows * (W >> 2);
-        Scope sc(c, s, "k_build_lm");
-        hipLaunchKernelGGL(k_build_lm_rows, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
+        SBM_LAUNCH(c, "k_build_lm", k_build_lm_rows, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -314,8 +344,7 @@ int launch_build_lm(sbm_ctx* c, hipStream_t s, const uint8_t* d_q, int rows, int
         const int tw = LM_GX * T, lw = tw + T - 1, lwp = (lw + 3) & ~3, lh = 2 * T - 1;
         const size_t smem = (size_t)lh * lwp + (size_t)lh * tw + (size_t)T * T * LM_GX;
         dim3 grid((W + LM_GX - 1) / LM_GX, H);
-        Scope sc(c, s, "k_build_lm");
-        hipLaunchKernelGGL(k_build_lm, grid, dim3(256), smem, s, d_q, rows, cols, T, W, H, d_lm, lm_stride);
+        SBM_LAUNCH(c, "k_build_lm", k_build_lm, grid, dim3(256), smem, s, d_q, rows, cols, T, W, H, d_lm, lm_stride);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -382,8 +411,7 @@ int ensure_foff(sbm_ctx* c, hipStream_t s)
     const int32_t* g = c->d_geo.as<int32_t>();
     const int64_t* st = (const int64_t*)((char*)c->d_geo.p + 3 * SBM_MAX_LEVELS * sizeof(int32_t));
     const int blocks = (int)std::min<int64_t>((c->n_features + 255) / 256, 8192);
-    Scope sc(c, s, "k_prep_features");
-    hipLaunchKernelGGL(k_prep_features, dim3(blocks), dim3(256), 0, s, c->d_fxy.as<uint32_t>(),
+    SBM_LAUNCH(c, "k_prep_features", k_prep_features, dim3(blocks), dim3(256), 0, s, c->d_fxy.as<uint32_t>(),
                        c->d_flabel.as<uint8_t>(), c->d_flevel.as<uint8_t>(), c->n_features, g,
                        g + SBM_MAX_LEVELS, g + 2 * SBM_MAX_LEVELS, st, c->d_foff.as<int32_t>());
     HIP_TRY(hipGetLastError());
@@ -409,9 +437,8 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
             const int pr = c->rows[l - 1], pc = c->cols[l - 1];
             // the image of level l was produced by level l-1's quantize launch (fused cv::pyrDown)
             if (mask) {
-                Scope sc(c, s, "k_resize_mask");
                 const int n = c->rows[l] * c->cols[l];
-                hipLaunchKernelGGL(k_resize_mask, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, mask, pr, pc,
+                SBM_LAUNCH(c, "k_resize_mask", k_resize_mask, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, mask, pr, pc,
                                    c->d_mask[l].as<uint8_t>(), c->rows[l], c->cols[l]);
                 HIP_TRY(hipGetLastError());
                 mask = c->d_mask[l].as<uint8_t>();
@@ -443,8 +470,7 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
             a.out_count = reset_count;
             c->counters_fresh = true;
         }
-        Scope sc(c, s, "k_build_lm");
-        hipLaunchKernelGGL(k_build_lm_rows, dim3(blocks), dim3(256), 0, s, a);
+        SBM_LAUNCH(c, "k_build_lm", k_build_lm_rows, dim3(blocks), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
     }
     c->levels_valid = c->L;
@@ -472,10 +498,9 @@ int enqueue_coarse(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap,
     if (n_active > 0) {
         const int T = c->cfg.T[lc], W = c->cols[lc] / T, H = c->rows[lc] / T;
         const int chunks = (W * H + COARSE_POS_PER_BLOCK - 1) / COARSE_POS_PER_BLOCK;
-        Scope sc(c, s, "k_similarity_coarse");
         for (int first = 0; first < n_active; first += 65535) {
             const int cnt = std::min(65535, n_active - first);
-            hipLaunchKernelGGL(k_similarity_coarse, dim3(chunks, cnt), dim3(256), 0, s, c->d_lm[lc].as<uint8_t>(),
+            SBM_LAUNCH(c, "k_similarity_coarse", k_similarity_coarse, dim3(chunks, cnt), dim3(256), 0, s, c->d_lm[lc].as<uint8_t>(),
                                c->lm_stride[lc], c->rows[lc], c->cols[lc], T, W, H, L, lc, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(),
                                c->d_foff.as<int32_t>(), c->d_active.as<int32_t>() + first, c->d_rawmin.as<int32_t>(),
                                c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
@@ -484,8 +509,7 @@ int enqueue_coarse(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap,
         HIP_TRY(hipGetLastError());
     }
     if (L == 1) {
-        Scope sc(c, s, "k_emit_coarse");
-        hipLaunchKernelGGL(k_emit_coarse, dim3(256), dim3(256), 0, s, c->d_cands.as<Cand>(), counters, (int)c->cand_cap,
+        SBM_LAUNCH(c, "k_emit_coarse", k_emit_coarse, dim3(256), dim3(256), 0, s, c->d_cands.as<Cand>(), counters, (int)c->cand_cap,
                            c->d_tls.as<DevTL>(), L, lc, c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(), d_out, d_count,
                            (int)cap, c->mirror_out, c->mirror_count);
         HIP_TRY(hipGetLastError());
@@ -500,8 +524,7 @@ int enqueue_local(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap, 
     int32_t* counters = c->d_counters.as<int32_t>();
     for (int l = L - 2; l >= 0; --l) {
         const int T = c->cfg.T[l], W = c->cols[l] / T, H = c->rows[l] / T;
-        Scope sc(c, s, "k_similarity_local");
-        hipLaunchKernelGGL(k_similarity_local, dim3(512), dim3(64 * LOCAL_WAVES), 0, s, c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
+        SBM_LAUNCH(c, "k_similarity_local", k_similarity_local, dim3(512), dim3(64 * LOCAL_WAVES), 0, s, c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
                            c->rows[l], c->cols[l], T, W, H, L, l, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(), c->d_foff.as<int32_t>(),
                            c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
                            c->d_cands.as<Cand>(), counters, (int)c->cand_cap, l == 0 ? 1 : 0, d_out, d_count, (int)cap,

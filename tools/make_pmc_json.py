@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection CSVs (separate passes, as the
+MI355X guide prescribes) into profiles/pmc_traffic.json: HBM-side bytes per launch, per kernel.
+FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads
+half the bytes of wide (16 B/lane) coalesced streaming reads; it is applied only to the kernels whose
+global reads are 16 B/lane (k_build_lm_rows, k_similarity_coarse); the others use <= 4 B/lane loads,
+for which the raw counter matched the known byte counts of this workload (k_quantize: 3.00 MiB read
+for a 3 MiB frame)."""
+import collections, csv, json, sys
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != counter:
+            continue
+        name = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0].replace('sbm::', '')
+        acc[name].append(float(r['Counter_Value']))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+fetch = per_kernel(sys.argv[1], 'FETCH_SIZE')
+write = per_kernel(sys.argv[2], 'WRITE_SIZE')
+wide = {'k_build_lm_rows', 'k_similarity_coarse'}
+out = {'_unit': 'bytes per launch (average over the launches of one step)', '_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes', '_raw_KiB': {}}
+alias = {'k_build_lm_rows': 'k_build_lm'}
+for k in sorted(set(fetch) | set(write)):
+    f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+    fc = f * (2.0 if k in wide else 1.0)
+    out[alias.get(k, k)] = (fc + w) * 1024.0
+    out['_raw_KiB'][alias.get(k, k)] = {'FETCH_SIZE': f, 'WRITE_SIZE': w, 'fetch_x2_correction': k in wide}
+json.dump(out, open(sys.argv[3], 'w'), indent=1)
+print(json.dumps(out, indent=1))
