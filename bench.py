@@ -30,7 +30,7 @@ ROWS = COLS = 1024
 N_TEMPLATES = 360
 THRESHOLD = 90.0
 T_LEVELS = (4, 8)
-PREFETCH = 4096  # match records copied to the host with the count, per step
+PREFETCH = 1024  # capacity (records) of the per-frame match list exchanged between ranks / sent to the host
 
 
 def load_workload(world: int):
@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--force-collective", action="store_true",
+                    help="rehearsal: run the N>1 code path (RCCL all-gathers + host copy) with whatever world size")
     ap.add_argument("--inflight", type=int, default=2,
                     help="frames in flight per GPU: independent engine contexts + HIP streams used round-robin "
                          "(1 = strictly one frame at a time; the single-stream figure is always reported too)")
@@ -112,14 +114,22 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    collective = world > 1 or args.force_collective
+    if collective:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     ts, frame = load_workload(world)
     first, count = sharding.partition(sharding.coarse_work(ts, ROWS, COLS, T_LEVELS), world)[rank]
 
     cap = PREFETCH
     d_img = torch.from_numpy(frame).to(dev)
+
+    REC = MATCH_DTYPE.itemsize
+    HDR = 16  # {n_matches, overflow} + padding, in front of the records: one buffer, one collective, one copy
+    BUF = HDR + cap * REC
 
     class Slot:
         """one frame in flight: its own engine context (device buffers), stream and result buffers"""
@@ -133,29 +143,39 @@ def main():
             # always an explicit stream: handle 0 would mean "the context's own stream" to the C ABI and
             # the result copies below must be ordered after the kernels
             self.stream = torch.cuda.Stream(device=dev)
-            self.d_out = torch.zeros(cap * MATCH_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-            self.d_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
-            self.gath_out = torch.zeros(world * cap * MATCH_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-            self.gath_cnt = torch.zeros(world * 2, dtype=torch.int32, device=dev)
-            self.h_out = torch.zeros(world * cap * MATCH_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
-            self.h_cnt = torch.zeros(world * 2, dtype=torch.int32).pin_memory()
-
-            if world == 1:
+            self.d_buf = torch.zeros(BUF, dtype=torch.uint8, device=dev)       # this rank: header + records
+            self.g_buf = torch.zeros(world * BUF, dtype=torch.uint8, device=dev)  # all ranks, gathered
+            self.h_buf = torch.zeros(world * BUF, dtype=torch.uint8).pin_memory()
+            if not collective:
                 # single GPU: the last kernel stores the match list straight into pinned host memory
-                self.ctx.set_result_mirror(self.h_out.data_ptr(), self.h_cnt.data_ptr())
+                self.ctx.set_result_mirror(self.h_buf.data_ptr() + HDR, self.h_buf.data_ptr())
+            else:
+                # one RCCL communicator per frame slot, bootstrapped over torch.distributed
+                uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, src=0)
+                self.ctx.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
 
         def run(self):
-            with torch.cuda.stream(self.stream):
-                self.ctx.match_device(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, self.d_out.data_ptr(), cap,
-                                      self.d_cnt.data_ptr(), stream=self.stream.cuda_stream)
-                if world > 1:
-                    dist.all_gather_into_tensor(self.gath_cnt, self.d_cnt)
-                    dist.all_gather_into_tensor(self.gath_out, self.d_out)
-                    self.h_cnt.copy_(self.gath_cnt, non_blocking=True)
-                    self.h_out.copy_(self.gath_out, non_blocking=True)
+            if collective:
+                # match of this rank's template shard + the exchange step (ncclAllGather over xGMI, issued by the
+                # library on the same stream) + copy of the gathered lists into pinned host memory
+                self.ctx.match_device_sharded(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, self.d_buf.data_ptr(), cap,
+                                              self.g_buf.data_ptr(), gathered_mirror=self.h_buf.data_ptr(),
+                                              stream=self.stream.cuda_stream)
+            else:
+                self.ctx.match_device(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, self.d_buf.data_ptr() + HDR, cap,
+                                      self.d_buf.data_ptr(), stream=self.stream.cuda_stream)
+
+        def host_counts(self):
+            return self.h_buf.numpy().reshape(world, BUF)[:, :8].copy().view(np.int32).reshape(world, 2)
+
+        def host_records(self):
+            return self.h_buf.numpy().reshape(world, BUF)[:, HDR:].copy().view(MATCH_DTYPE).reshape(world, cap)
 
     slots = [Slot(None) for i in range(max(1, args.inflight))]
-    ctx, h_cnt, h_out, d_out, d_cnt = slots[0].ctx, slots[0].h_cnt, slots[0].h_out, slots[0].d_out, slots[0].d_cnt
+    ctx = slots[0].ctx
     stream = slots[0].stream
     torch.cuda.synchronize()
     step_no = [0]
@@ -166,7 +186,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -178,7 +198,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -199,18 +219,18 @@ def main():
     ref_counts = None
     for rep in range(3):
         for sl in slots:
-            sl.h_cnt.zero_()
+            sl.h_buf.zero_()
             sl.run()
             torch.cuda.synchronize()
-            c = sl.h_cnt.numpy().reshape(world, 2).copy()
+            c = sl.host_counts()
             if ref_counts is None:
                 ref_counts = c
             if not np.array_equal(c, ref_counts) or c[:, 0].min() <= 0:
                 raise SystemExit(f"unstable match counts: {c.tolist()} vs {ref_counts.tolist()}")
-    counts = h_cnt.numpy().reshape(world, 2)
+    counts = slots[0].host_counts()
     if (counts[:, 1] != 0).any() or (counts[:, 0] > cap).any():
         raise SystemExit(f"match list overflow: {counts.tolist()}")
-    recs = h_out.numpy().view(MATCH_DTYPE).reshape(world, cap)
+    recs = slots[0].host_records()
     matches = np.concatenate([recs[r, : counts[r, 0]] for r in range(world)])
     n_matches = len(capi.canonicalize(matches))
 
@@ -220,8 +240,8 @@ def main():
     per_kernel = {}
     prof_steps = min(args.steps, 50)
     for _ in range(prof_steps):
-        ctx.match_device(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, d_out.data_ptr(), cap,
-                         d_cnt.data_ptr(), stream=stream.cuda_stream)
+        ctx.match_device(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, slots[0].d_buf.data_ptr() + HDR, cap,
+                         slots[0].d_buf.data_ptr(), stream=stream.cuda_stream)
         torch.cuda.synchronize()
         for name, ms in ctx.timings():
             per_kernel.setdefault(name, []).append(ms)
@@ -282,7 +302,7 @@ def main():
                 "templates_total": total_templates,
                 "templates_per_gpu": count,
                 "frame": [ROWS, COLS, 3],
-                "parallelism": f"template-shard x{world}" + (" + RCCL all-gather of match lists" if world > 1 else ""),
+                "parallelism": f"template-shard x{world}" + (" + RCCL all-gather of match lists" if collective else ""),
                 "frames_in_flight": len(slots),
                 "ms_per_step_one_frame_at_a_time": single_ms,
                 "matches_distinct": n_matches,
@@ -313,7 +333,7 @@ def main():
         print(json.dumps(out))
     for sl in slots:
         sl.ctx.close()
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

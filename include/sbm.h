@@ -115,6 +115,31 @@ int sbm_set_graph_mode(sbm_ctx* ctx, int32_t enabled);
  * mirror must hold cap records / two int32 and outlive the calls using it. */
 int sbm_set_result_mirror(sbm_ctx* ctx, void* mirror_out, void* mirror_count);
 
+/* ---- multi-GPU: template shards + one RCCL exchange step -------------------
+ * The reference's only parallelism is the OpenMP loop over templates whose
+ * per-thread match vectors are concatenated by a reduction
+ * (line2Dup.cpp:1166-1170).  Analogue: one context (process) per GPU, each with
+ * a template range (sbm_select_range), and ONE collective per frame: an
+ * ncclAllGather over xGMI of the per-rank lists, issued by the library on the
+ * same stream as the kernels.  librccl is resolved with dlopen on first use.
+ *
+ *   sbm_comm_unique_id   rank 0: 128-byte id to hand to every rank (any transport)
+ *   sbm_comm_init        every rank: join the communicator on the context's GPU
+ *   sbm_match_device_sharded
+ *        d_local    : SBM_SHARD_HEADER_BYTES + cap * 24 bytes, this rank's list:
+ *                     int32 {n_matches, overflow, 0, 0} then the records
+ *        d_gathered : world * (that size), all ranks' lists in rank order
+ *        gathered_mirror : optional device-visible copy of d_gathered (pinned host)
+ */
+#define SBM_COMM_ID_BYTES 128
+#define SBM_SHARD_HEADER_BYTES 16
+int sbm_comm_unique_id(void* id_out);
+int sbm_comm_init(sbm_ctx* ctx, int32_t world, int32_t rank, const void* id);
+int sbm_comm_destroy(sbm_ctx* ctx);
+int sbm_match_device_sharded(sbm_ctx* ctx, const void* d_img, int32_t rows, int32_t cols, int32_t stride,
+                             int32_t channels, const void* d_mask, float threshold, void* d_local,
+                             int64_t cap, void* d_gathered, void* gathered_mirror, void* stream);
+
 /* Detector::match epilogue (line2Dup.cpp:1142-1145) in canonical form: sort by
  * (similarity desc, template_id asc, class_idx asc, y asc, x asc), drop exact
  * duplicates.  Host-side, in place; returns the new count. */

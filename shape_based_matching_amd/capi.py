@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "sbm_compute_response_maps", "sbm_linearize", "sbm_similarity", "sbm_similarity_local",
     "sbm_set_profiling", "sbm_get_timings", "sbm_coarse_bytes", "sbm_get_stats",
     "sbm_set_result_mirror", "sbm_set_graph_mode",
+    "sbm_comm_unique_id", "sbm_comm_init", "sbm_comm_destroy", "sbm_match_device_sharded",
 ]
 
 
@@ -92,6 +93,10 @@ def lib() -> C.CDLL:
     L.sbm_get_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.sbm_set_result_mirror.argtypes = [vp, vp, vp]
     L.sbm_set_graph_mode.argtypes = [vp, i32]
+    L.sbm_comm_unique_id.argtypes = [vp]
+    L.sbm_comm_init.argtypes = [vp, i32, i32, vp]
+    L.sbm_comm_destroy.argtypes = [vp]
+    L.sbm_match_device_sharded.argtypes = [vp, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp, vp]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
         if name not in ("sbm_last_error", "sbm_destroy", "sbm_canonicalize"):
@@ -192,6 +197,26 @@ class Context:
         """Device-visible (e.g. pinned host) addresses that receive a copy of every result."""
         _check(lib().sbm_set_result_mirror(self._h, C.c_void_p(mirror_out) if mirror_out else None,
                                            C.c_void_p(mirror_count) if mirror_count else None))
+
+    # -- multi-GPU exchange (RCCL inside the library) -------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(lib().sbm_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, world: int, rank: int, uid: bytes):
+        assert len(uid) == 128
+        _check(lib().sbm_comm_init(self._h, world, rank, C.c_char_p(uid)))
+
+    def match_device_sharded(self, d_img: int, rows: int, cols: int, stride: int, channels: int, threshold: float,
+                             d_local: int, cap: int, d_gathered: int, gathered_mirror: int = 0, stream: int = 0,
+                             d_mask: int = 0):
+        _check(lib().sbm_match_device_sharded(self._h, C.c_void_p(d_img), rows, cols, stride, channels,
+                                              C.c_void_p(d_mask) if d_mask else None, C.c_float(threshold),
+                                              C.c_void_p(d_local), cap, C.c_void_p(d_gathered),
+                                              C.c_void_p(gathered_mirror) if gathered_mirror else None,
+                                              C.c_void_p(stream) if stream else None))
 
     def set_graph_mode(self, on: bool):
         _check(lib().sbm_set_graph_mode(self._h, 1 if on else 0))

@@ -3,6 +3,7 @@
 // entry point fails with SBM_ERR_HIP when no GPU is usable.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <climits>
@@ -21,6 +22,7 @@ using namespace sbm;
 namespace {
 
 thread_local std::string g_err;
+void (*g_rccl_destroy_hook)(sbm_ctx*) = nullptr; // set once librccl is loaded
 
 int fail(int code, const char* fmt, ...)
 {
@@ -114,6 +116,8 @@ struct sbm_ctx {
 
     // candidates / results
     DevBuf d_cands, d_counters, d_out, d_outcount;
+    void* comm = nullptr;  // ncclComm_t of this context (sbm_comm_init)
+    int comm_world = 0, comm_rank = 0;
     sbm_match_rec* mirror_out = nullptr; // optional device-visible mirror of the results (sbm_set_result_mirror)
     int32_t* mirror_count = nullptr;
     DevBuf d_scratch;
@@ -685,6 +689,7 @@ void sbm_destroy(sbm_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device_id);
     (void)hipDeviceSynchronize();
+    if (c->comm && g_rccl_destroy_hook) g_rccl_destroy_hook(c);
     c->drop_graphs();
     for (int l = 0; l < SBM_MAX_LEVELS; ++l)
         if (c->ev_fork[l]) (void)hipEventDestroy(c->ev_fork[l]);
@@ -1200,6 +1205,112 @@ int sbm_set_result_mirror(sbm_ctx* c, void* mirror_out, void* mirror_count)
     c->mirror_count = (int32_t*)mirror_count;
     return 0;
 }
+
+} // extern "C" (reopened below)
+
+// ---- RCCL exchange step (resolved at run time: the library itself does not link librccl) ----
+namespace {
+struct Id128 { // ncclUniqueId is passed by value
+    char b[128];
+};
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+int rccl_load()
+{
+    if (g_rccl.h) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names)
+        if ((g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!g_rccl.h) return fail(SBM_ERR_HIP, "cannot load librccl: %s", dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(g_rccl.h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(g_rccl.h, "ncclCommInitRank");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.h, "ncclAllGather");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.h, "ncclGetErrorString");
+    g_rccl_destroy_hook = [](sbm_ctx* c) {
+        if (c->comm) g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
+    };
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+        g_rccl.h = nullptr;
+        return fail(SBM_ERR_HIP, "librccl lacks the expected entry points");
+    }
+    return 0;
+}
+const char* rccl_err(int rc) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "nccl error"; }
+} // namespace
+
+extern "C" int sbm_comm_unique_id(void* id_out)
+{
+    if (!id_out) return fail(SBM_ERR_INVALID, "null argument");
+    if (int e = rccl_load()) return e;
+    int rc = g_rccl.GetUniqueId(id_out);
+    if (rc) return fail(SBM_ERR_HIP, "ncclGetUniqueId: %s", rccl_err(rc));
+    return 0;
+}
+
+extern "C" int sbm_comm_init(sbm_ctx* c, int32_t world, int32_t rank, const void* id)
+{
+    if (!c || !id || world < 1 || rank < 0 || rank >= world) return fail(SBM_ERR_INVALID, "bad communicator arguments");
+    if (int e = rccl_load()) return e;
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    if (c->comm) {
+        g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    Id128 uid;
+    memcpy(uid.b, id, 128);
+    int rc = g_rccl.CommInitRank(&c->comm, world, uid, rank);
+    if (rc) return fail(SBM_ERR_HIP, "ncclCommInitRank: %s", rccl_err(rc));
+    c->comm_world = world;
+    c->comm_rank = rank;
+    return 0;
+}
+
+extern "C" int sbm_comm_destroy(sbm_ctx* c)
+{
+    if (!c) return fail(SBM_ERR_INVALID, "null context");
+    if (c->comm && g_rccl.CommDestroy) {
+        (void)hipDeviceSynchronize();
+        g_rccl.CommDestroy(c->comm);
+    }
+    c->comm = nullptr;
+    c->comm_world = 0;
+    return 0;
+}
+
+extern "C" int sbm_match_device_sharded(sbm_ctx* c, const void* d_img, int32_t rows, int32_t cols, int32_t stride, int32_t channels,
+                                        const void* d_mask, float threshold, void* d_local, int64_t cap, void* d_gathered,
+                                        void* gathered_mirror, void* stream)
+{
+    if (!c || !d_local || !d_gathered) return fail(SBM_ERR_INVALID, "null argument");
+    if (!c->comm) return fail(SBM_ERR_STATE, "sbm_comm_init has not been called on this context");
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const size_t bytes = (size_t)SBM_SHARD_HEADER_BYTES + (size_t)cap * sizeof(sbm_match_rec);
+    // this rank's shard: {n_matches, overflow, 0, 0} header followed by the records
+    if (int e = sbm_match_device(c, d_img, rows, cols, stride, channels, d_mask, threshold, (char*)d_local + SBM_SHARD_HEADER_BYTES, cap,
+                                 d_local, s))
+        return e;
+    // the one exchange step of the path: every rank's list to every rank, over xGMI, on the same stream
+    int rc = g_rccl.AllGather(d_local, d_gathered, bytes, /* ncclUint8 */ 1, c->comm, s);
+    if (rc) return fail(SBM_ERR_HIP, "ncclAllGather: %s", rccl_err(rc));
+    if (gathered_mirror) {
+        const size_t total = bytes * (size_t)c->comm_world;
+        hipLaunchKernelGGL(k_copy_bytes, dim3((unsigned)std::min<size_t>((total / 16 + 255) / 256 + 1, 1024)), dim3(256), 0, s,
+                           (const uint8_t*)d_gathered, (uint8_t*)gathered_mirror, total);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" {
 
 int sbm_coarse_bytes(sbm_ctx* c, int64_t* bytes)
 {

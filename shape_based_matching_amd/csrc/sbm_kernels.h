@@ -910,6 +910,15 @@ __device__ __forceinline__ void accumulate_features16(const uint8_t* __restrict_
     }
 }
 
+// plain byte copy (gathered match lists -> pinned host mirror); n multiple of 8 by construction
+__global__ __launch_bounds__(256) void k_copy_bytes(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t n)
+{
+    const size_t n8 = n / 8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256)
+        ((uint64_t*)dst)[i] = ((const uint64_t*)src)[i];
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[n8 * 8 + threadIdx.x] = src[n8 * 8 + threadIdx.x];
+}
+
 // zero the per-call counters (one launch instead of two memsets)
 __global__ void k_reset(int32_t* __restrict__ counters, int32_t* __restrict__ out_count)
 {

@@ -89,3 +89,37 @@ def test_match_device_back_to_back_frames(oracle, ctx_factory, case1):
         c = cnts[k].cpu().numpy()
         assert c[0] == len(want) and c[1] == 0
         assert key(outs[k].cpu().numpy().view(MATCH_DTYPE)[: c[0]]) == key(want)
+
+
+def test_match_device_sharded_world1(oracle, ctx_factory, case1):
+    """the multi-GPU entry point (template shard + ncclAllGather issued by the library) on a
+    one-rank communicator: header + records of the gathered buffer, device and pinned-host copy"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    ts = case1["templates"].subset(range(300, 361, 2))
+    frame = frame_of(case1)
+    ctx = ctx_factory()
+    ctx.upload_templates(ts)
+    ctx.select_range(5, 20)  # this "rank" owns templates 5..24 of the set
+    ctx.comm_init(1, 0, ctx.comm_unique_id())
+    cap, hdr, rec = 512, 16, MATCH_DTYPE.itemsize
+    stream = torch.cuda.Stream(device=dev)
+    d_img = torch.from_numpy(frame).to(dev)
+    d_local = torch.zeros(hdr + cap * rec, dtype=torch.uint8, device=dev)
+    d_gath = torch.zeros(hdr + cap * rec, dtype=torch.uint8, device=dev)
+    h_gath = torch.zeros(hdr + cap * rec, dtype=torch.uint8).pin_memory()
+    for _ in range(3):
+        with torch.cuda.stream(stream):
+            ctx.match_device_sharded(d_img.data_ptr(), frame.shape[0], frame.shape[1], frame.shape[1] * 3, 3, 85.0,
+                                     d_local.data_ptr(), cap, d_gath.data_ptr(), gathered_mirror=h_gath.data_ptr(),
+                                     stream=stream.cuda_stream)
+        stream.synchronize()
+    pyr = oracle.Pyramid.build(frame, [4, 8], 30.0)
+    shard = ts.subset(range(5, 25))
+    want = pyr.match(shard.levels, shard.features, shard.class_idx, shard.template_id, 85.0)
+    assert len(want) > 0
+    for buf in (d_gath.cpu().numpy(), h_gath.numpy()):
+        n, overflow = buf[:8].view(np.int32)
+        assert overflow == 0 and n == len(want)
+        assert key(buf[hdr:].view(MATCH_DTYPE)[:n]) == key(want)
