@@ -169,6 +169,11 @@ int sbm_level_dims(sbm_ctx* ctx, int32_t level, int32_t* rows, int32_t* cols);
 int sbm_match_templates(sbm_ctx* ctx, float threshold, sbm_match_rec* out_host, int64_t cap,
                         int64_t* n_out);
 
+/* Asynchronous form: the template loop against the resident pyramid on `stream`, results into
+ * caller-provided device buffers (as sbm_match_device). */
+int sbm_match_templates_device(sbm_ctx* ctx, float threshold, void* d_out, int64_t cap, void* d_count,
+                               void* stream);
+
 /* ---- single reference functions (stage entry points; host arrays) --------
  * Each runs the HIP kernel that replaces one reference function and copies the
  * result back, so it can be tested (and adopted) on its own. */

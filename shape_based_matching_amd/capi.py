@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "sbm_compute_response_maps", "sbm_linearize", "sbm_similarity", "sbm_similarity_local",
     "sbm_set_profiling", "sbm_get_timings", "sbm_coarse_bytes", "sbm_get_stats",
     "sbm_set_result_mirror", "sbm_set_graph_mode",
+    "sbm_match_templates_device",
     "sbm_comm_unique_id", "sbm_comm_init", "sbm_comm_destroy", "sbm_match_device_sharded",
 ]
 
@@ -93,6 +94,7 @@ def lib() -> C.CDLL:
     L.sbm_get_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.sbm_set_result_mirror.argtypes = [vp, vp, vp]
     L.sbm_set_graph_mode.argtypes = [vp, i32]
+    L.sbm_match_templates_device.argtypes = [vp, f32, vp, i64, vp, vp]
     L.sbm_comm_unique_id.argtypes = [vp]
     L.sbm_comm_init.argtypes = [vp, i32, i32, vp]
     L.sbm_comm_destroy.argtypes = [vp]
@@ -254,6 +256,10 @@ class Context:
         n = C.c_int64(0)
         _check(lib().sbm_match_templates(self._h, C.c_float(threshold), _p(out), self._cap, C.byref(n)))
         return out[: n.value].copy()
+
+    def match_templates_device(self, threshold: float, d_out: int, cap: int, d_count: int, stream: int = 0):
+        _check(lib().sbm_match_templates_device(self._h, C.c_float(threshold), C.c_void_p(d_out), cap, C.c_void_p(d_count),
+                                                C.c_void_p(stream) if stream else None))
 
     # -- single reference functions -------------------------------------------
     def quantized_orientations(self, img: np.ndarray, weak: float, want_float: bool = True):

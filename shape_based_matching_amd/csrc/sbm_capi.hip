@@ -871,6 +871,16 @@ int sbm_match_device(sbm_ctx* c, const void* d_img, int32_t rows, int32_t cols, 
     return 0;
 }
 
+int sbm_match_templates_device(sbm_ctx* c, float threshold, void* d_out, int64_t cap, void* d_count, void* stream)
+{
+    if (!c || !d_out || !d_count) return fail(SBM_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (!c->have_thr || memcmp(&threshold, &c->thr_cached, 4) != 0 || c->foff_dirty) HIP_TRY(hipDeviceSynchronize());
+    if (c->profiling) c->clear_timings();
+    return enqueue_templates(c, s, threshold, (sbm_match_rec*)d_out, cap, (int32_t*)d_count);
+}
+
 int sbm_set_graph_mode(sbm_ctx* c, int32_t enabled)
 {
     if (!c) return fail(SBM_ERR_INVALID, "null context");
