@@ -255,6 +255,7 @@ struct YNode {
 };
 YNode parse_yaml(const std::string& text);
 std::string read_text_file(const std::string& path, bool* ok);
+bool write_text_file(const std::string& path, const std::string& text);
 } // namespace detail
 
 class FileNode;

@@ -4,6 +4,8 @@
 
 #include <cctype>
 
+#include <zlib.h>
+
 namespace cv {
 namespace detail {
 
@@ -162,13 +164,41 @@ YNode parse_yaml(const std::string& text)
     return parse_block(lines, pos, lines[0].indent);
 }
 
+static bool ends_with_gz(const std::string& p) { return p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0; }
+
+// plain or gzip-compressed text (the reference writes templates as "%s.yaml.gz", test_jabil.cpp:114)
 std::string read_text_file(const std::string& path, bool* ok)
 {
+    if (ends_with_gz(path)) {
+        gzFile g = gzopen(path.c_str(), "rb");
+        if (ok) *ok = g != nullptr;
+        std::string out;
+        if (!g) return out;
+        char buf[1 << 16];
+        int n;
+        while ((n = gzread(g, buf, sizeof buf)) > 0) out.append(buf, (size_t)n);
+        gzclose(g);
+        return out;
+    }
     std::ifstream f(path, std::ios::binary);
     if (ok) *ok = (bool)f;
     std::ostringstream ss;
     ss << f.rdbuf();
     return ss.str();
+}
+
+bool write_text_file(const std::string& path, const std::string& text)
+{
+    if (ends_with_gz(path)) {
+        gzFile g = gzopen(path.c_str(), "wb");
+        if (!g) return false;
+        const bool ok = gzwrite(g, text.data(), (unsigned)text.size()) == (int)text.size();
+        gzclose(g);
+        return ok;
+    }
+    std::ofstream f(path, std::ios::binary);
+    f << text;
+    return (bool)f;
 }
 } // namespace detail
 
@@ -178,8 +208,6 @@ bool FileStorage::open(const std::string& filename, int mode)
     release();
     path_ = filename;
     writing_ = (mode & 1) != 0;
-    if (filename.size() > 3 && filename.compare(filename.size() - 3, 3, ".gz") == 0)
-        CV_Error(Error::StsBadArg, "cvlite FileStorage: .gz files are not supported (gunzip first)");
     if (writing_) {
         out_.str("");
         out_ << "%YAML:1.0\n---\n";
@@ -199,10 +227,7 @@ bool FileStorage::open(const std::string& filename, int mode)
 
 void FileStorage::release()
 {
-    if (opened_ && writing_) {
-        std::ofstream f(path_, std::ios::binary);
-        f << out_.str();
-    }
+    if (opened_ && writing_) detail::write_text_file(path_, out_.str());
     opened_ = false;
     writing_ = false;
 }

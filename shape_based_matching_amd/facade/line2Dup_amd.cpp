@@ -615,7 +615,7 @@ Detector* Detector::getInstance(std::string path)
     FileNode classes_fn = fs["classes"];
     for (FileNodeIterator it = classes_fn.begin(); it != classes_fn.end(); ++it) ids.push_back((std::string)*it);
     const std::string dir = (std::string)fs["templates_dir"];
-    d->readClasses(ids, dir + "/%s.yaml");
+    d->readClasses(ids, dir + "/%s.yaml.gz"); // line2Dup.cpp:1390
     Detector::instance = d;
     return d;
 }

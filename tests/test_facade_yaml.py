@@ -37,3 +37,19 @@ def test_cpp_reads_the_reference_yaml_files(tmp_path, case, name):
     r = subprocess.run([DEMO, "convert", f"{REFERENCE}/test/case{case}/%s_templ.yaml", name, out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert same(read_class_yaml(out % name), read_class_yaml(f"{REFERENCE}/test/case{case}/{name}_templ.yaml"))
+
+
+@pytest.mark.skipif(not os.path.exists(DEMO), reason="facade demo not built")
+def test_cpp_yaml_gz_roundtrip(tmp_path, case1):
+    """templates_%s.yml.gz is the reference's default format (line2Dup.h:310-312)"""
+    ts = case1["templates"].subset(range(0, 361, 60))
+    ts.template_id[:] = np.arange(ts.n_templates)
+    src = str(tmp_path / "%s_in.yaml.gz")
+    write_class_yaml(ts, src % "test")  # the Python writer gzips by extension
+    out = str(tmp_path / "%s_out.yml.gz")
+    r = subprocess.run([DEMO, "convert", src, "test", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    import gzip
+
+    assert gzip.open(out % "test", "rt").readline().startswith("%YAML")
+    assert same(read_class_yaml(out % "test"), ts)
