@@ -675,7 +675,7 @@ int sbm_create(const sbm_config* cfg, sbm_ctx** out)
             return fail(SBM_ERR_HIP, "event creation failed");
         }
     int rc = 0;
-    if ((rc = c->d_cands.ensure((size_t)c->cand_cap * sizeof(Cand))) || (rc = c->d_counters.ensure(64, true)) ||
+    if ((rc = c->d_cands.ensure((size_t)c->cand_cap * sizeof(Cand))) || (rc = c->d_counters.ensure(256, true)) ||
         (rc = c->d_out.ensure((size_t)c->cand_cap * sizeof(sbm_match_rec))) || (rc = c->d_outcount.ensure(16, true))) {
         sbm_destroy(c);
         return rc;

@@ -670,7 +670,7 @@ struct LmArgs {
 __global__ __launch_bounds__(256) void k_build_lm_rows(const LmArgs a)
 {
     if (blockIdx.x == 0 && a.counters) {
-        if (threadIdx.x < 8) a.counters[threadIdx.x] = 0;
+        if (threadIdx.x < 40) a.counters[threadIdx.x] = 0;
         if (threadIdx.x < 2 && a.out_count) a.out_count[threadIdx.x] = 0;
     }
     int l = 0;
@@ -753,6 +753,7 @@ __device__ __forceinline__ int template_positions(const DevTL& tl, int W, int H,
 
 constexpr int SIM_POS_PER_BLOCK = 1024; // 256 lanes x 4 positions
 constexpr int FB = 8;                   // features per batch: FB independent loads in flight per lane
+constexpr int FBL = 16;                 // refinement pass: few features per wave, all in flight at once
 constexpr int FB16 = 8;                 // same for the 16-byte variant (coarse pass)
 
 // Sum `count` features starting at `f0` into packed 16-bit lanes.  Each lane
@@ -802,7 +803,7 @@ __device__ __forceinline__ void accumulate_features(const uint8_t* __restrict__ 
 #pragma unroll
             for (int k = 0; k < n; ++k) acc += v[k];
             pending += n;
-            if (pending + FB > 63) {
+            if (pending + FBL > 63) {
                 lo += acc & 0x00ff00ffu;
                 hi += (acc >> 8) & 0x00ff00ffu;
                 acc = 0;
@@ -810,7 +811,8 @@ __device__ __forceinline__ void accumulate_features(const uint8_t* __restrict__ 
             }
         };
         int u = 0;
-        for (; u + FB <= nb; u += FB) batch(std::integral_constant<int, FB>{}, u);
+        for (; u + FBL <= nb; u += FBL) batch(std::integral_constant<int, FBL>{}, u);
+        if (FBL > 8 && nb - u >= 8) { batch(std::integral_constant<int, 8>{}, u); u += 8; }
         if (nb - u >= 4) { batch(std::integral_constant<int, 4>{}, u); u += 4; }
         if (nb - u >= 2) { batch(std::integral_constant<int, 2>{}, u); u += 2; }
         if (nb - u >= 1) batch(std::integral_constant<int, 1>{}, u);
@@ -922,7 +924,7 @@ __global__ __launch_bounds__(256) void k_copy_bytes(const uint8_t* __restrict__ 
 // zero the per-call counters (one launch instead of two memsets)
 __global__ void k_reset(int32_t* __restrict__ counters, int32_t* __restrict__ out_count)
 {
-    if (threadIdx.x < 8) counters[threadIdx.x] = 0; // [0] candidates [1] - [2,3] refine bytes [4] blocks done
+    if (threadIdx.x < 40) counters[threadIdx.x] = 0; // [0] candidates [2,3] refine bytes [4] arrivals [8..39] sub-arrivals
     if (threadIdx.x < 2) out_count[threadIdx.x] = 0;
 }
 
@@ -1033,8 +1035,13 @@ __device__ __forceinline__ void publish_counts(int32_t* __restrict__ counters, i
     if (threadIdx.x == 0) {
         bool last = n_work_blocks == 0;
         if (!last) {
-            __threadfence();
-            last = atomicAdd(&counters[4], 1) == n_work_blocks - 1;
+            // two-level arrival (32 sub-counters): arrivals on one address serialise at ~25 ns each
+            const int sub = (int)blockIdx.x & 31;
+            const int expect = (n_work_blocks - sub + 31) / 32; // working blocks with this residue
+            const int groups = n_work_blocks < 32 ? n_work_blocks : 32;
+            // no fence: the last block only reads out_count (device-scope atomics); the records themselves
+            // become visible to the host and to later kernels at the end of the kernel
+            if (atomicAdd(&counters[8 + sub], 1) == expect - 1) last = atomicAdd(&counters[4], 1) == groups - 1;
         }
         if (last) {
             const int n_out = atomicAdd(out_count, 0);
