@@ -201,3 +201,37 @@ def test_full_size_properties(oracle, ctx_factory):
     assert ctx.coarse_bytes() == pyr.coarse_bytes(ts.levels, ts.features)
     want = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 90.0, n_threads=8)
     assert multiset(a) == multiset(want)
+
+
+def test_strided_rows_and_roi_views(oracle, ctx_factory, case1):
+    """the C ABI takes a row stride: a frame that is a view into a wider buffer (cv::Mat ROI)"""
+    import ctypes as C
+
+    from shape_based_matching_amd.capi import _check, lib
+
+    ts = case1["templates"].subset(range(320, 361, 4))
+    frame = case1_frame(case1)[:640, :768]
+    wide = np.zeros((640, 1000, 3), np.uint8)
+    wide[:, 100:868] = frame
+    view = wide[:, 100:868]  # not contiguous: stride 3000 bytes
+    ctx = ctx_factory()
+    ctx.upload_templates(ts)
+    out = np.empty(4096, MATCH_DTYPE)
+    n = C.c_int64(0)
+    _check(lib().sbm_match(ctx._h, C.c_void_p(view.ctypes.data), 640, 768, wide.strides[0], 3, None, C.c_float(88.0),
+                           out.ctypes.data_as(C.c_void_p), len(out), C.byref(n)))
+    pyr = oracle.Pyramid.build(np.ascontiguousarray(frame), [4, 8], 30.0)
+    want = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 88.0)
+    assert len(want) > 0 and multiset(out[: n.value]) == multiset(want)
+
+
+def test_no_templates_and_empty_selection(ctx_factory, case1):
+    ctx = ctx_factory()
+    frame = np.ascontiguousarray(case1_frame(case1)[:320, :384])
+    with pytest.raises(capi.SbmError) as e:  # nothing uploaded
+        ctx.match(frame, 90.0)
+    assert e.value.code == -4
+    ts = case1["templates"].subset(range(3))
+    ctx.upload_templates(ts)
+    ctx.select_range(0, 0)  # an empty shard is legal: no matches
+    assert len(ctx.match(frame, 90.0)) == 0

@@ -143,3 +143,95 @@ def test_pyrdown_constant_and_size(oracle):
                 for i in range(5):
                     acc += K[i] * K[j] * int(img[refl(2 * y + j - 2, 16), refl(2 * x + i - 2, 20)])
             assert d[y, x] == (acc + 128) >> 8
+
+
+def numpy_match_class(lms, strides, rows, cols, T, ts, threshold):
+    """SURVEY Appendix B (the specification of line2Dup.cpp:1170-1296) written directly in numpy/Python,
+    independently of oracle/sbm_oracle.c's control flow: flat linear memories in, pre-dedup multiset out."""
+    L = len(T)
+    f32 = np.float32
+    out = []
+
+    def base(l, x, y, label):
+        W, H = cols[l] // T[l], rows[l] // T[l]
+        return label * strides[l] + ((y % T[l]) * T[l] + x % T[l]) * W * H + (y // T[l]) * W + x // T[l]
+
+    def score(raw, nf):
+        return f32(f32(raw) * f32(100.0)) / f32(4 * nf)
+
+    for t in range(ts.n_templates):
+        l = L - 1
+        W, H = cols[l] // T[l], rows[l] // T[l]
+        lv = ts.levels[t, l]
+        nf = int(lv["n_features"])
+        wf, hf = int((int(lv["width"]) - 1) / T[l]) + 1, int((int(lv["height"]) - 1) / T[l]) + 1
+        npos = (H - hf) * W + (W - wf) + 1
+        raw = np.zeros(W * H, np.int64)
+        flat = lms[l].ravel()
+        for f in ts.feats_of(t, l):
+            x, y, lab = int(f["x"]), int(f["y"]), int(f["label"])
+            if 0 <= x < cols[l] and 0 <= y < rows[l] and npos > 0:
+                b = base(l, x, y, lab)
+                raw[:npos] += flat[b : b + npos]
+        off = T[l] // 2 + (T[l] % 2 - 1)
+        cands = []
+        for j in range(W * H):
+            s = score(raw[j], nf) if nf else f32("nan")
+            if s > f32(threshold):
+                cands.append([(j % W) * T[l] + off, (j // W) * T[l] + off, s, int(raw[j])])
+        for l in range(L - 2, -1, -1):
+            W = cols[l] // T[l]
+            lv = ts.levels[t, l]
+            nf = int(lv["n_features"])
+            border, off = 8 * T[l], T[l] // 2 + (T[l] % 2 - 1)
+            max_x, max_y = cols[l] - int(lv["width"]) - border, rows[l] - int(lv["height"]) - border
+            flat = lms[l].ravel()
+            for m in cands:
+                x, y = m[0] * 2 + 1, m[1] * 2 + 1
+                x, y = max(x, border), max(y, border)
+                x, y = min(x, max_x), min(y, max_y)
+                ox, oy = (int(x / T[l]) - 8) * T[l], (int(y / T[l]) - 8) * T[l]
+                patch = np.zeros((16, 16), np.int64)
+                for f in ts.feats_of(t, l):
+                    fx, fy, lab = int(f["x"]) + ox, int(f["y"]) + oy, int(f["label"])
+                    if fx < 0 or fy < 0 or fx >= cols[l] or fy >= rows[l]:
+                        continue
+                    b = base(l, fx, fy, lab)
+                    for r in range(16):
+                        patch[r] += flat[b + r * W : b + r * W + 16]
+                best, br, bc, braw = f32(0), -1, -1, 0
+                for r in range(16):
+                    for c in range(16):
+                        s = score(patch[r, c], nf) if nf else f32("nan")
+                        if s > best:
+                            best, br, bc, braw = s, r, c, int(patch[r, c])
+                m[0] = (int(x / T[l]) - 8 + bc) * T[l] + off
+                m[1] = (int(y / T[l]) - 8 + br) * T[l] + off
+                m[2], m[3] = best, braw
+            cands = [m for m in cands if not (m[2] < f32(threshold))]
+        for m in cands:
+            out.append((m[0], m[1], float(m[2]), m[3], int(ts.class_idx[t]), int(ts.template_id[t])))
+    return sorted(out)
+
+
+def test_match_class_against_numpy_specification(oracle):
+    """third, independent implementation of the template loop (besides the C oracle and the HIP kernels)"""
+    T = [4, 8]
+    maps, ts = synth.stage_b(77, 256, 320, T, 10, [70, 36], templ_size=64, plant_every=2, density_permille=30)
+    # corner cases: overrun features (x == width, width % T == 0), a feature outside the frame, a u8-path level
+    ts.levels[1, 1]["width"] = 32
+    ts.levels[1, 1]["height"] = 32
+    o = int(ts.levels[1, 1]["feature_offset"])
+    ts.features["x"][o : o + 3] = 32
+    ts.features["y"][o + 3 : o + 6] = 32
+    ts.features["x"][int(ts.levels[2, 0]["feature_offset"])] = 900
+    pyr = oracle.Pyramid.from_quantized(maps, T)
+    lms = [pyr.lm(l) for l in range(2)]
+    strides = [pyr.lm_stride(l) for l in range(2)]
+    rows, cols = [256, 128], [320, 160]
+    for thr in (80.0, 55.0):
+        want = numpy_match_class(lms, strides, rows, cols, T, ts, thr)
+        got = sorted((int(r["x"]), int(r["y"]), float(r["similarity"]), int(r["raw"]), int(r["class_idx"]), int(r["template_id"]))
+                     for r in pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr))
+        assert len(want) > 0
+        assert got == want
