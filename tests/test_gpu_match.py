@@ -210,7 +210,7 @@ def test_strided_rows_and_roi_views(oracle, ctx_factory, case1):
     from shape_based_matching_amd.capi import _check, lib
 
     ts = case1["templates"].subset(range(320, 361, 4))
-    frame = case1_frame(case1)[:640, :768]
+    frame = synth.embed(case1["test"], 640, 768, 80, 80)
     wide = np.zeros((640, 1000, 3), np.uint8)
     wide[:, 100:868] = frame
     view = wide[:, 100:868]  # not contiguous: stride 3000 bytes
@@ -227,7 +227,7 @@ def test_strided_rows_and_roi_views(oracle, ctx_factory, case1):
 
 def test_no_templates_and_empty_selection(ctx_factory, case1):
     ctx = ctx_factory()
-    frame = np.ascontiguousarray(case1_frame(case1)[:320, :384])
+    frame = synth.embed(case1["test"], 640, 768, 80, 80)
     with pytest.raises(capi.SbmError) as e:  # nothing uploaded
         ctx.match(frame, 90.0)
     assert e.value.code == -4
