@@ -183,6 +183,10 @@ int sbm_match_templates_device(sbm_ctx* ctx, float threshold, void* d_out, int64
 int sbm_quantized_orientations(sbm_ctx* ctx, const uint8_t* img_host, int32_t rows, int32_t cols,
                                int32_t stride, int32_t channels, float weak_threshold,
                                float* magnitude, uint8_t* angle, float* angle_ori);
+/* The 16-bin quantisation of hysteresisGradient (line2Dup.cpp:225: convertTo(CV_8U, 16/360) of the
+ * phase image) as the match path computes it: an integer rule on the Sobel gradient (gx, gy), exact for
+ * |gx|, |gy| <= 1020.  q16[i] in 0..16. */
+int sbm_orientation_bins(sbm_ctx* ctx, const int16_t* gx, const int16_t* gy, int64_t n, uint8_t* q16);
 /* cv::pyrDown as called by ColorGradientPyramid::pyrDown (line2Dup.cpp:431-433). */
 int sbm_pyrdown(sbm_ctx* ctx, const uint8_t* img_host, int32_t rows, int32_t cols, int32_t stride,
                 int32_t channels, uint8_t* out_host);

@@ -48,6 +48,7 @@ def lib() -> C.CDLL:
         L.sbo_sobel3.argtypes = [vp, i32, i32, i32, vp, vp]
         L.sbo_fast_atan2_deg.argtypes = [f32, f32]
         L.sbo_fast_atan2_deg.restype = f32
+        L.sbo_orientation_bins.argtypes = [vp, vp, i64, vp]
         L.sbo_pyrdown.argtypes = [vp, i32, i32, i32, i32, vp]
         L.sbo_quantized_orientations.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp, vp]
         L.sbo_spread.argtypes = [vp, i32, i32, i32, vp]
@@ -112,6 +113,15 @@ def sobel3(sm: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
 
 def fast_atan2_deg(y: float, x: float) -> float:
     return float(lib().sbo_fast_atan2_deg(C.c_float(y), C.c_float(x)))
+
+
+def orientation_bins(dx: np.ndarray, dy: np.ndarray) -> np.ndarray:
+    """16-bin index of cvRound(fastAtan2(dy, dx) * 16/360) for int16 gradient arrays."""
+    dx = np.ascontiguousarray(dx, np.int16)
+    dy = np.ascontiguousarray(dy, np.int16)
+    out = np.empty(dx.shape, np.uint8)
+    lib().sbo_orientation_bins(_p(dx), _p(dy), dx.size, _p(out))
+    return out
 
 
 def pyrdown(img: np.ndarray) -> np.ndarray:

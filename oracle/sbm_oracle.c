@@ -105,6 +105,17 @@ float sbo_fast_atan2_deg(float y, float x)
     return a;
 }
 
+/* The 16-bin orientation index hysteresisGradient derives from the phase image (:225):
+ * saturate_cast<uchar>(cvRound(fastAtan2(dy, dx) * (16/360))), vectorised over integer gradients. */
+void sbo_orientation_bins(const int16_t* dx, const int16_t* dy, int64_t n, uint8_t* q16)
+{
+    const float scale = (float)(16.0 / 360.0);
+    for (int64_t i = 0; i < n; ++i) {
+        long v = lrintf(sbo_fast_atan2_deg((float)dy[i], (float)dx[i]) * scale);
+        q16[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
 /* cv::pyrDown(src, dst, Size(cols/2, rows/2)), BORDER_DEFAULT (REFLECT_101):
  * [1 4 6 4 1]^2 / 256, (sum + 128) >> 8.  line2Dup.cpp:431-433. */
 void sbo_pyrdown(const uint8_t* src, int rows, int cols, int ch, int stride, uint8_t* dst)

@@ -35,6 +35,7 @@ extern "C" {
 void sbo_gaussian7(const uint8_t* src, int rows, int cols, int ch, int stride, uint8_t* dst);
 void sbo_sobel3(const uint8_t* sm, int rows, int cols, int ch, int16_t* dx, int16_t* dy);
 float sbo_fast_atan2_deg(float y, float x);
+void sbo_orientation_bins(const int16_t* dx, const int16_t* dy, int64_t n, uint8_t* q16);
 void sbo_pyrdown(const uint8_t* src, int rows, int cols, int ch, int stride, uint8_t* dst);
 void sbo_resize_nearest_u8(const uint8_t* src, int rows, int cols, uint8_t* dst, int drows, int dcols);
 /* quantizedOrientations + hysteresisGradient.  magnitude/angle_ori may be NULL. */

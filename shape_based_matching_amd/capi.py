@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "sbm_compute_response_maps", "sbm_linearize", "sbm_similarity", "sbm_similarity_local",
     "sbm_set_profiling", "sbm_get_timings", "sbm_coarse_bytes", "sbm_get_stats",
     "sbm_set_result_mirror", "sbm_set_graph_mode",
-    "sbm_match_templates_device",
+    "sbm_match_templates_device", "sbm_orientation_bins",
     "sbm_comm_unique_id", "sbm_comm_init", "sbm_comm_destroy", "sbm_match_device_sharded",
 ]
 
@@ -83,6 +83,7 @@ def lib() -> C.CDLL:
     L.sbm_match_templates.argtypes = [vp, f32, vp, i64, C.POINTER(i64)]
     L.sbm_quantized_orientations.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]
     L.sbm_pyrdown.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    L.sbm_orientation_bins.argtypes = [vp, vp, vp, i64, vp]
     L.sbm_spread.argtypes = [vp, vp, i32, i32, i32, vp]
     L.sbm_compute_response_maps.argtypes = [vp, vp, i32, i32, vp]
     L.sbm_linearize.argtypes = [vp, vp, i32, i32, i32, vp]
@@ -269,6 +270,13 @@ class Context:
         ori = np.empty((r, c), np.float32) if want_float else None
         _check(lib().sbm_quantized_orientations(self._h, _p(img), r, c, c * ch, ch, C.c_float(weak), _p(mag), _p(ang), _p(ori)))
         return mag, ang, ori
+
+    def orientation_bins(self, gx: np.ndarray, gy: np.ndarray) -> np.ndarray:
+        gx = np.ascontiguousarray(gx, np.int16)
+        gy = np.ascontiguousarray(gy, np.int16)
+        out = np.empty(gx.shape, np.uint8)
+        _check(lib().sbm_orientation_bins(self._h, _p(gx), _p(gy), gx.size, _p(out)))
+        return out
 
     def pyrdown(self, img: np.ndarray) -> np.ndarray:
         img, r, c, ch = _img(img)

@@ -1044,6 +1044,28 @@ done:
     return rc;
 }
 
+int sbm_orientation_bins(sbm_ctx* c, const int16_t* gx, const int16_t* gy, int64_t n, uint8_t* q16)
+{
+    if (!c || !gx || !gy || !q16 || n < 0) return fail(SBM_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    DevBuf a, b, o;
+    int rc = 0;
+    if ((rc = a.ensure((size_t)n * 2)) || (rc = b.ensure((size_t)n * 2)) || (rc = o.ensure((size_t)n))) goto done;
+    if (hipMemcpy(a.p, gx, (size_t)n * 2, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(b.p, gy, (size_t)n * 2, hipMemcpyHostToDevice) != hipSuccess) {
+        rc = fail(SBM_ERR_HIP, "upload failed");
+        goto done;
+    }
+    hipLaunchKernelGGL(k_orientation_bins, dim3((unsigned)std::min<int64_t>((n + 255) / 256 + 1, 8192)), dim3(256), 0, c->stream,
+                       a.as<int16_t>(), b.as<int16_t>(), n, o.as<uint8_t>());
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(q16, o.p, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(SBM_ERR_HIP, "orientation_bins failed: %s", hipGetErrorString(hipGetLastError()));
+done:
+    a.release();
+    b.release();
+    o.release();
+    return rc;
+}
+
 int sbm_pyrdown(sbm_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t ch, uint8_t* out)
 {
     if (!c || !img || !out || rows < 2 || cols < 2 || ch < 1 || ch > 4) return fail(SBM_ERR_INVALID, "bad argument");

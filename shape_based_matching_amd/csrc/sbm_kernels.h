@@ -106,6 +106,29 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
+// 16-bin orientation index of an integer gradient, equal for every |gx|, |gy| <= 1020 (the range of a 3x3
+// Sobel on 8-bit data) to saturate_cast<uchar>(cvRound(fastAtan2(gy, gx) * 16/360)) of line2Dup.cpp:225:
+// per octant the float pipeline is a step function of min/max with the same two thresholds, which lie in
+// (182/915, 73/367] and (661/989, 264/395] (tools/derive_orientation_thresholds.py scans all pairs; the
+// parity tests check all 2041^2 of them on the GPU).  ~15 integer ops instead of a division + polynomial.
+__device__ __forceinline__ int orientation_bin16(int gx, int gy)
+{
+    const int ax = gx < 0 ? -gx : gx, ay = gy < 0 ? -gy : gy;
+    const int mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    int k = 0;
+    if (mx > 0) k = (__mul24(mn, 367) >= __mul24(73, mx) ? 1 : 0) + (__mul24(mn, 395) >= __mul24(264, mx) ? 1 : 0);
+    if (ay > ax) k = 4 - k;
+    if (gx < 0) k = 8 - k;
+    if (gy < 0) k = 16 - k;
+    return k;
+}
+
+__global__ __launch_bounds__(256) void k_orientation_bins(const int16_t* __restrict__ gx, const int16_t* __restrict__ gy,
+                                                          int64_t n, uint8_t* __restrict__ q16)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) q16[i] = (uint8_t)orientation_bin16(gx[i], gy[i]);
+}
+
 // ---------------------------------------------------------------------------
 // k_quantize: one block = one 16 x 64 output tile, 4 pixels per lane in every
 // phase, planar (per-channel) LDS images read and written as dwords.
@@ -353,9 +376,15 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
             uint32_t code = 0;
             if (r >= 0 && r < rows && c >= 0 && c < cols) {
                 const float mag = (float)bm[m];
-                const float ang = fast_atan2_deg((float)by[m], (float)bx[m]);
-                int q16 = __float2int_rn(__fmul_rn(ang, (float)(16.0 / 360.0)));
-                q16 = q16 < 0 ? 0 : (q16 > 255 ? 255 : q16);
+                float ang = 0.f;
+                int q16;
+                if (WITH_FLOAT) { // the unquantised angle is an output here: the float pipeline itself
+                    ang = fast_atan2_deg((float)by[m], (float)bx[m]);
+                    q16 = __float2int_rn(__fmul_rn(ang, (float)(16.0 / 360.0)));
+                    q16 = q16 < 0 ? 0 : (q16 > 255 ? 255 : q16);
+                } else {
+                    q16 = orientation_bin16(bx[m], by[m]);
+                }
                 const bool ring = (r == 0) || (r == rows - 1) || (c == 0) || (c == cols - 1);
                 code = (uint32_t)(ring ? 0 : (q16 & 7)) | ((mag > thr_sq) ? 8u : 0u);
                 if (WITH_FLOAT) {

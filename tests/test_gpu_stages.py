@@ -156,3 +156,15 @@ def test_invalid_arguments_fail_loudly(ctx_factory):
         ctx.upload_templates(ts)
     with pytest.raises(capi.SbmError):  # no pyramid yet
         ctx.match_templates(90.0)
+
+
+def test_orientation_bins_exhaustive(oracle, ctx_factory):
+    """the match path bins orientations with an integer rule instead of fastAtan2: every Sobel gradient
+    pair (|gx|, |gy| <= 1020: 2041^2 of them) against the float pipeline of line2Dup.cpp:225/:327"""
+    ctx = ctx_factory()
+    g = np.arange(-1020, 1021, dtype=np.int16)
+    gx, gy = np.meshgrid(g, g)
+    want = oracle.orientation_bins(gx.ravel(), gy.ravel())
+    got = ctx.orientation_bins(gx.ravel(), gy.ravel())
+    assert np.array_equal(got, want)
+    assert set(np.unique(want)) == set(range(17))

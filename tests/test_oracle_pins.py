@@ -121,3 +121,17 @@ def test_golden_templates_match_reference_yaml():
         g = TemplateSet.load_npz(os.path.join(GOLDEN, f"case{case}_templates.npz"))
         assert np.array_equal(ts.levels, g.levels) and np.array_equal(ts.features, g.features)
         assert ts.class_ids == g.class_ids
+
+
+def test_integer_orientation_rule_equals_float_pipeline(oracle):
+    """CPU-side statement of the rule k_quantize uses (tools/derive_orientation_thresholds.py)"""
+    g = np.arange(-1020, 1021, dtype=np.int16)
+    gx, gy = np.meshgrid(g, g)
+    gx, gy = gx.ravel().astype(np.int64), gy.ravel().astype(np.int64)
+    ax, ay = np.abs(gx), np.abs(gy)
+    mx, mn = np.maximum(ax, ay), np.minimum(ax, ay)
+    k = ((mn * 367 >= 73 * mx) & (mx > 0)).astype(np.int64) + ((mn * 395 >= 264 * mx) & (mx > 0))
+    k = np.where(ay > ax, 4 - k, k)
+    k = np.where(gx < 0, 8 - k, k)
+    k = np.where(gy < 0, 16 - k, k)
+    assert np.array_equal(k, oracle.orientation_bins(gx.astype(np.int16), gy.astype(np.int16)).astype(np.int64))
