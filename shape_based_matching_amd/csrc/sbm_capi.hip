@@ -501,7 +501,22 @@ int enqueue_coarse(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap,
     const int n_active = (int)c->h_active.size();
     if (n_active > 0) {
         const int T = c->cfg.T[lc], W = c->cols[lc] / T, H = c->rows[lc] / T;
-        const int chunks = (W * H + COARSE_POS_PER_BLOCK - 1) / COARSE_POS_PER_BLOCK;
+        int chunks = (W * H + COARSE_POS_PER_BLOCK - 1) / COARSE_POS_PER_BLOCK;
+        if (c->thr_cached >= 0.f) {
+            // every raw_min is >= 1, so positions past a template's span (score 0) are never candidates:
+            // launch only the chunks some template reaches; a multiple of 8 of them lets the kernel give
+            // each XCD a contiguous, equally loaded range of chunks (its L2 then holds one slice of the
+            // linear memories)
+            int max_npos = 0;
+            for (int32_t t : c->h_active) {
+                const DevTL& tl = c->h_tls[(size_t)t * L + lc];
+                const int wf = (tl.width - 1) / T + 1, hf = (tl.height - 1) / T + 1;
+                max_npos = std::max(max_npos, (H - hf) * W + (W - wf) + 1);
+            }
+            int need = std::max(1, (std::min(std::max(max_npos, 0), W * H) + COARSE_POS_PER_BLOCK - 1) / COARSE_POS_PER_BLOCK);
+            if (need >= 8) need = (need + 7) / 8 * 8;
+            chunks = std::min(need, (chunks + 7) / 8 * 8);
+        }
         for (int first = 0; first < n_active; first += 65535) {
             const int cnt = std::min(65535, n_active - first);
             SBM_LAUNCH(c, "k_similarity_coarse", k_similarity_coarse, dim3(chunks, cnt), dim3(256), 0, s, c->d_lm[lc].as<uint8_t>(),

@@ -973,11 +973,25 @@ __global__ __launch_bounds__(256) void k_similarity_coarse(
 {
     __shared__ uint32_t s_red[4][8][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = active[blockIdx.y];
+    // XCD-aware (chunk, template) assignment.  Workgroups are dealt to the 8 XCDs round-robin by linear id,
+    // and each XCD has its own 4 MiB L2: give XCD x the position chunks [x*cpx, (x+1)*cpx) of EVERY
+    // template, so that one L2 only ever sees the slice of the linear memories those chunks read
+    // (chunk span + template extent) instead of all of them.  Pure speed: any mapping is correct.
+    int chunk_id = blockIdx.x, templ_slot = blockIdx.y;
+    if ((gridDim.x & 7) == 0) {
+        const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+        const int cpx = (int)gridDim.x >> 3;
+        const int xcd = lin & 7, slot = lin >> 3;
+        templ_slot = slot / cpx;
+        // the chunk ranges rotate over the XCDs every 64 templates: ranges past the templates' span are
+        // empty, and this spreads them evenly while an XCD still works on one slice for 64 templates
+        chunk_id = ((xcd + (templ_slot >> 6)) & 7) * cpx + slot % cpx;
+    }
+    const int t = active[templ_slot];
     const DevTL tl = tls[(size_t)t * L + lc];
     const int npos = template_positions(tl, W, H, T);
     const int rmin = raw_min[(size_t)t * L + lc];
-    const int base = blockIdx.x * COARSE_POS_PER_BLOCK;
+    const int base = chunk_id * COARSE_POS_PER_BLOCK;
     const int total = W * H;
     if (base >= total) return;
     if (base >= npos && rmin > 0) return; // beyond the span every score is 0
