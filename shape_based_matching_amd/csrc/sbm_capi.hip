@@ -763,13 +763,14 @@ int sbm_upload_templates(sbm_ctx* c, int32_t n_templates, const sbm_template_lev
         cls[t] = class_idx ? class_idx[t] : 0;
         tid[t] = template_id ? template_id[t] : t;
     }
+    HIP_TRY(hipDeviceSynchronize()); // the buffers below may be re-allocated while frames are in flight
     int rc = 0;
     if ((rc = c->d_tls.ensure(tls.size() * sizeof(DevTL))) || (rc = c->d_fxy.ensure(fxy.size() * 4)) ||
         (rc = c->d_flabel.ensure(flabel.size())) || (rc = c->d_flevel.ensure(flevel.size())) ||
         (rc = c->d_foff.ensure(fxy.size() * 4)) || (rc = c->d_class.ensure(cls.size() * 4)) ||
         (rc = c->d_tid.ensure(tid.size() * 4)))
         return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipDeviceSynchronize()); // frames still in flight on the caller's streams read the old tables
     if (!tls.empty()) HIP_TRY(hipMemcpy(c->d_tls.p, tls.data(), tls.size() * sizeof(DevTL), hipMemcpyHostToDevice));
     if (!fxy.empty()) {
         HIP_TRY(hipMemcpy(c->d_fxy.p, fxy.data(), fxy.size() * 4, hipMemcpyHostToDevice));
@@ -795,8 +796,8 @@ int sbm_upload_templates(sbm_ctx* c, int32_t n_templates, const sbm_template_lev
 static int set_active(sbm_ctx* c, std::vector<int32_t>& act)
 {
     HIP_TRY(hipSetDevice(c->cfg.device_id));
+    HIP_TRY(hipDeviceSynchronize()); // frames in flight read the current selection
     if (int e = c->d_active.ensure(std::max<size_t>(act.size(), 1) * 4)) return e;
-    HIP_TRY(hipStreamSynchronize(c->stream));
     if (!act.empty()) HIP_TRY(hipMemcpy(c->d_active.p, act.data(), act.size() * 4, hipMemcpyHostToDevice));
     c->h_active.swap(act);
     c->drop_graphs(); // grid sizes depend on the active set
