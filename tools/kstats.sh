@@ -8,8 +8,8 @@ import csv, collections
 rows = list(csv.DictReader(open("$GRAFT_REPO_ROOT/gpurun_out/ks_$1/ks_kernel_trace.csv")))
 d = collections.defaultdict(list)
 for r in rows:
-    d[(r['Kernel_Name'].split('(')[0].replace('void ','')[:32], r['Grid_Size'])].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
+    d[(r['Kernel_Name'].split('(')[0].replace('void ','')[:32], r['Grid_Size_X'])].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
 for k, v in sorted(d.items()):
-    if 'sbm' in k[0]:
+    if 'k_' in k[0]:
         v = sorted(v); print("$1", k[0], k[1], "n=%d median %.2f us  p10 %.2f  p90 %.2f" % (len(v), v[len(v)//2], v[len(v)//10], v[9*len(v)//10]))
 PY
