@@ -33,7 +33,7 @@ T_LEVELS = (4, 8)
 PREFETCH = 1024  # capacity (records) of the per-frame match list exchanged between ranks / sent to the host
 
 
-def load_workload(world: int):
+def load_workload(world: int, frame_kind: str = "case1"):
     from shape_based_matching_amd import synth
     from shape_based_matching_amd.templates import TemplateSet
 
@@ -46,7 +46,13 @@ def load_workload(world: int):
         shards.append(s)
     ts = TemplateSet.concat(shards)
     img = np.load(os.path.join(golden, "case1_test_bgr.npz"))["bgr"]
-    frame = synth.embed(img, ROWS, COLS, (ROWS - img.shape[0]) // 2, (COLS - img.shape[1]) // 2)
+    if frame_kind == "tiled":
+        # no constant region anywhere: the test image repeated over the whole canvas (robustness figure,
+        # none of k_quantize's flat-tile shortcuts fire)
+        reps = (-(-ROWS // img.shape[0]), -(-COLS // img.shape[1]), 1)
+        frame = np.ascontiguousarray(np.tile(img, reps)[:ROWS, :COLS])
+    else:
+        frame = synth.embed(img, ROWS, COLS, (ROWS - img.shape[0]) // 2, (COLS - img.shape[1]) // 2)
     return ts, frame
 
 
@@ -94,9 +100,12 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: run the N>1 code path (RCCL all-gathers + host copy) with whatever world size")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="frames in flight per GPU: independent engine contexts + HIP streams used round-robin "
                          "(1 = strictly one frame at a time; the single-stream figure is always reported too)")
+    ap.add_argument("--frame", choices=("case1", "tiled"), default="case1",
+                    help="case1: the reference's test image centred on a black canvas (BASELINE configs[1]); "
+                         "tiled: the same image repeated over the whole canvas (no constant regions)")
     args = ap.parse_args()
 
     import torch
@@ -121,7 +130,7 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    ts, frame = load_workload(world)
+    ts, frame = load_workload(world, args.frame)
     first, count = sharding.partition(sharding.coarse_work(ts, ROWS, COLS, T_LEVELS), world)[rank]
 
     cap = PREFETCH
@@ -294,8 +303,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "reference case1 test image (test/case1/test.png) centred on a black 1024x1024 BGR canvas; "
-                    "case1 rotation templates 0..359 (test/case1/test_templ.yaml)",
+            "data": ("reference case1 test image (test/case1/test.png) centred on a black 1024x1024 BGR canvas; "
+                     if args.frame == "case1" else
+                     "reference case1 test image (test/case1/test.png) tiled over the whole 1024x1024 BGR canvas; ")
+                    + "case1 rotation templates 0..359 (test/case1/test_templ.yaml)",
             "config": {
                 "workload": "case1 on MI355X: 1024x1024x3 frame x 360 templates per GPU (131/71 features), "
                             "pyramid T={4,8}, threshold 90, match list gathered to the host every step",

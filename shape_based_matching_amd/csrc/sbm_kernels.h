@@ -146,6 +146,37 @@ __global__ __launch_bounds__(256) void k_orientation_bins(const int16_t* __restr
 //      orientation bins, 'strong' flag (mag > weak^2).
 //   E  3x3 majority vote (>= 5 of 9) around strong pixels -> one-hot byte.
 // ---------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. every wave would
+// sit at the barrier until its outstanding GLOBAL stores are acknowledged; the tiles below exchange data
+// through LDS alone, so lgkmcnt(0) is the whole requirement.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Diagnostic build only (tools/quantize_probe.hip defines SBM_QSTAMP): thread 0 of every tile stores
+// s_memtime (and s_memrealtime at entry / exit) at the phase boundaries into a buffer nothing else reads.
+#ifdef SBM_QSTAMP
+__device__ unsigned long long* g_qstamp = nullptr;
+#ifdef SBM_QSTAMP_LIGHT /* entry and exit only */
+#define QSTAMP_ON(i) ((i) == 0 || (i) == 6)
+#else
+#define QSTAMP_ON(i) true
+#endif
+#define QSTAMP(i)                                                                               \
+    if (QSTAMP_ON(i) && threadIdx.x == 0 && g_qstamp) {                                         \
+        unsigned long long* q_ = g_qstamp + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 48; \
+        if (i == 0 || i == 6) q_[i] = __builtin_amdgcn_s_memrealtime();                         \
+        q_[8 + i] = __builtin_amdgcn_s_memtime();                                               \
+        if (i == 0) {                                                                           \
+            q_[16] = __builtin_amdgcn_s_getreg(4 | (31 << 11));                                 \
+            q_[17] = __builtin_amdgcn_s_getreg(20 | (31 << 11));                                \
+        }                                                                                       \
+    }
+#define QSTAMP_WAVES(base)                                        \
+    if (QSTAMP_ON(1) && (threadIdx.x & 63) == 0 && g_qstamp)      \
+        g_qstamp[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 48 + (base) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime();
+#else
+#define QSTAMP(i)
+#define QSTAMP_WAVES(base)
+#endif
 constexpr int QN = 1024; // threads per tile: short per-wave instruction streams, 16 waves hide each other's latency
 constexpr int QS_W = 80; // source tile width  (cols C0-8 .. C0+71)
 constexpr int QH_W = 72; // h / smoothed / q tile width (cols C0-4 .. C0+67)
@@ -154,6 +185,43 @@ typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
 {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b), c, false);
+}
+
+typedef short ss2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(ss2_t, a), __builtin_bit_cast(ss2_t, b), c, false);
+}
+// packed 2 x 16-bit lanes in a dword (wrap-around; the same bits for signed and unsigned operands)
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) + __builtin_bit_cast(us2_t, b))); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) - __builtin_bit_cast(us2_t, b))); }
+__device__ __forceinline__ uint32_t pk_2a_plus_b(uint32_t a, uint32_t b)
+{
+    const us2_t two = {2, 2};
+    return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) * two + __builtin_bit_cast(us2_t, b)));
+}
+
+// Vote word 1 << (4 * label) of a packed integer gradient v = (gx & 0xffff) | gy << 16, label = the
+// 8-bin orientation (orientation_bin16(gx, gy) & 7).  In the first quadrant the 16-bin index is the number
+// of bin boundaries below the direction, four sign tests of linear forms in (|gx|, |gy|) (same two
+// thresholds as orientation_bin16, mirrored about the diagonal); the other quadrants map k -> (8-k)&7 when
+// exactly one of gx, gy is negative.  A zero gradient is bin 0.
+__device__ __forceinline__ uint32_t vote_word(uint32_t v)
+{
+    const ss2_t sv = __builtin_bit_cast(ss2_t, v);
+    const uint32_t av = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(sv, (ss2_t)(-sv))); // (|gx|, |gy|)
+    const uint32_t u1 = (uint32_t)sdot2(av, (uint32_t)(uint16_t)(-73) | (367u << 16), 0);   // 367|gy| -  73|gx| >= 0
+    const uint32_t u2 = (uint32_t)sdot2(av, (uint32_t)(uint16_t)(-264) | (395u << 16), 0);  // 395|gy| - 264|gx| >= 0
+    const uint32_t u3 = (uint32_t)sdot2(av, (uint32_t)(uint16_t)(-395) | (264u << 16), -1); // 264|gy| - 395|gx| >  0
+    const uint32_t u4 = (uint32_t)sdot2(av, (uint32_t)(uint16_t)(-367) | (73u << 16), -1);  //  73|gy| - 367|gx| >  0
+    uint32_t neg = u1 >> 31; // collect the four sign bits
+    neg = __builtin_amdgcn_alignbit(neg, u2, 31);
+    neg = __builtin_amdgcn_alignbit(neg, u3, 31);
+    neg = __builtin_amdgcn_alignbit(neg, u4, 31);
+    const int sh = 16 - 4 * __builtin_popcount(neg);          // 4 * k, k = 0..4
+    const int m = (int)((v << 16) ^ v) >> 31;                   // -1 iff exactly one component is negative
+    const uint32_t w = 1u << (((sh ^ m) - m) & 31);             // k -> (8 - k) & 7
+    return v ? w : 1u;
 }
 
 template <int CH, bool WITH_FLOAT>
@@ -166,10 +234,15 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
     __shared__ uint32_t s_src[CH][QS_R][QS_W / 4]; // u8 x4
     __shared__ uint32_t s_h[CH][QS_R][QH_W / 2];   // u16 x2
     __shared__ uint32_t s_sm[CH][QM_R][QH_W / 4];  // u8 x4
-    __shared__ uint32_t s_q[QQ_R][QH_W / 4];       // u8 x4: bin | strong << 3
+    __shared__ __attribute__((aligned(16))) uint32_t s_w[QQ_R][QH_W]; // vote word 1 << 4*label per pixel
+    __shared__ uint32_t s_st[QQ_R][QH_W / 4];      // u8 x4: non-zero = magnitude above the weak threshold
+    __shared__ uint32_t s_pyr[QT_R / 2][QT_C / 2 * CH / 4]; // pyrDown of the tile, interleaved channels, as dwords
+    __shared__ uint32_t s_nonflat;
     const int tid = threadIdx.x;
     const int R0 = blockIdx.y * QT_R, C0 = blockIdx.x * QT_C;
     const bool interior = R0 >= 5 && R0 + QT_R + 5 <= rows && C0 >= 8 && C0 + QT_C + 8 <= cols;
+    QSTAMP(0)
+    if (tid == 0) s_nonflat = 0;
 
     // ---- A: source tile -> planar LDS (rows clamped; a 4-pixel group that sticks out of the image
     //         left or right takes the per-byte clamped path = BORDER_REPLICATE) ----
@@ -199,7 +272,8 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
+    QSTAMP(1)
 
     // ---- P: pyrDown of this tile (8 x 32 outputs), REFLECT_101 at the image border ----
     if (pyr_out && tid < 256) {
@@ -247,7 +321,7 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
                 }
             }
 #pragma unroll
-            for (int k = 0; k < CH; ++k) pyr_out[((size_t)oy * dcols + ox) * CH + k] = (uint8_t)((accs[k] + 128) >> 8);
+            for (int k = 0; k < CH; ++k) ((uint8_t*)&s_pyr[yy][0])[xx * CH + k] = (uint8_t)((accs[k] + 128) >> 8);
         }
     }
 
@@ -255,6 +329,7 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
     //      no pixel passes `mag > weak^2` and the whole output tile is 0 (padding / saturated background:
     //      the reference's own demo pads the frame with 250 black pixels, test.cpp:344-347).
     //      WITH_FLOAT keeps the full path so that magnitude / angle are written everywhere. ----
+    bool tile_flat = false;
     if (!WITH_FLOAT && thr_sq >= 0.f) {
         bool flat = true;
 #pragma unroll
@@ -262,22 +337,43 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
             const uint32_t ref = (s_src[k][0][0] & 0xffu) * 0x01010101u;
             for (int it = tid; it < QS_R * (QS_W / 4); it += QN) flat = flat && (s_src[k][it / (QS_W / 4)][it % (QS_W / 4)] == ref);
         }
-        if (__syncthreads_and(flat)) {
-            const int er = tid >> 4, g = tid & 15;
-            const int r = R0 + er;
-            if (tid < 256 && r < rows) {
-                uint8_t* o = out + (size_t)r * cols + C0 + 4 * g;
-                if (C0 + 4 * g + 3 < cols && ((((size_t)r * cols + C0 + 4 * g) & 3) == 0)) {
-                    *(uint32_t*)o = 0;
-                } else {
-                    for (int m = 0; m < 4; ++m)
-                        if (C0 + 4 * g + m < cols) o[m] = 0;
-                }
+        if (!flat) s_nonflat = 1; // benign race: every writer stores the same value
+        tile_flat = true;
+    }
+    if (pyr_out || tile_flat) lds_barrier();
+    if (tile_flat) tile_flat = s_nonflat == 0;
+    // the tile of the next pyramid level leaves as dwords (row segments of 32 * CH bytes)
+    if (pyr_out && tid < (QT_R / 2) * (QT_C / 2 * CH / 4)) {
+        const int yy = tid / (QT_C / 2 * CH / 4), w = tid - yy * (QT_C / 2 * CH / 4);
+        const int oy = (R0 >> 1) + yy, drows = rows >> 1, dcols = cols >> 1;
+        const int b0 = (C0 >> 1) * CH + 4 * w; // byte column in the destination row
+        if (oy < drows && b0 < dcols * CH) {
+            uint8_t* o = pyr_out + (size_t)oy * dcols * CH + b0;
+            const uint32_t v = s_pyr[yy][w];
+            if (b0 + 4 <= dcols * CH && (((uintptr_t)o) & 3) == 0) {
+                *(uint32_t*)o = v;
+            } else {
+                for (int m = 0; m < 4; ++m)
+                    if (b0 + m < dcols * CH) o[m] = (uint8_t)(v >> (8 * m));
             }
-            return;
         }
     }
+    if (tile_flat) {
+        const int er = tid >> 4, g = tid & 15;
+        const int r = R0 + er;
+        if (tid < 256 && r < rows) {
+            uint8_t* o = out + (size_t)r * cols + C0 + 4 * g;
+            if (C0 + 4 * g + 3 < cols && ((((size_t)r * cols + C0 + 4 * g) & 3) == 0)) {
+                *(uint32_t*)o = 0;
+            } else {
+                for (int m = 0; m < 4; ++m)
+                    if (C0 + 4 * g + m < cols) o[m] = 0;
+            }
+        }
+        return;
+    }
 
+    QSTAMP(2)
     // ---- B: horizontal 7-tap: output x (image col C0-4+x) reads source bytes x+1 .. x+7 ----
     for (int it = tid; it < CH * QS_R * (QH_W / 4); it += QN) {
         const int k = it / (QS_R * (QH_W / 4)), rem = it - k * (QS_R * (QH_W / 4));
@@ -296,28 +392,41 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
         s_h[k][r][2 * g] = h0 | (h1 << 16);
         s_h[k][r][2 * g + 1] = h2 | (h3 << 16);
     }
-    __syncthreads();
+    lds_barrier();
+    QSTAMP(3)
 
-    // ---- C: vertical 7-tap over s_h rows jr .. jr+6, two pixels (one dword column) per item ----
-    for (int it = tid; it < CH * QM_R * (QH_W / 2); it += QN) {
-        const int k = it / (QM_R * (QH_W / 2)), rem = it - k * (QM_R * (QH_W / 2));
-        const int jr = rem / (QH_W / 2), d = rem - jr * (QH_W / 2);
-        uint32_t a[7];
+    // ---- C: vertical 7-tap over s_h rows jr .. jr+6; an item = one dword column (two pixels) x CG consecutive
+    //         output rows, so the CG+6 source rows and the (row j, row j+1) pairings are shared ----
+    constexpr int CG = 5;
+    static_assert(QM_R % CG == 0, "row groups tile the smoothed rows");
+    for (int it = tid; it < CH * (QM_R / CG) * (QH_W / 2); it += QN) {
+        const int kg = it / (QH_W / 2), d = it - kg * (QH_W / 2);
+        const int k = kg / (QM_R / CG), jr0 = (kg - k * (QM_R / CG)) * CG;
+        uint32_t a[CG + 6];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) a[j] = s_h[k][jr + j][d];
-        const uint32_t K01 = 8u | (28u << 16), K23 = 56u | (72u << 16), K45 = 56u | (28u << 16);
-        // (row j, row j+1) pairs of the same pixel: low halves / high halves
-        uint32_t lo = udot2(__builtin_amdgcn_perm(a[1], a[0], 0x05040100u), K01, 32768u);
-        uint32_t hi = udot2(__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), K01, 32768u);
-        lo = udot2(__builtin_amdgcn_perm(a[3], a[2], 0x05040100u), K23, lo);
-        hi = udot2(__builtin_amdgcn_perm(a[3], a[2], 0x07060302u), K23, hi);
-        lo = udot2(__builtin_amdgcn_perm(a[5], a[4], 0x05040100u), K45, lo);
-        hi = udot2(__builtin_amdgcn_perm(a[5], a[4], 0x07060302u), K45, hi);
-        lo += 8u * (a[6] & 0xffffu);
-        hi += 8u * (a[6] >> 16);
-        ((uint16_t*)&s_sm[k][jr][0])[d] = (uint16_t)((lo >> 16) | ((hi >> 16) << 8));
+        for (int j = 0; j < CG + 6; ++j) a[j] = s_h[k][jr0 + j][d];
+        uint32_t plo[CG + 5], phi[CG + 5]; // (row j, row j+1) of the left / right pixel
+#pragma unroll
+        for (int j = 0; j < CG + 5; ++j) {
+            plo[j] = __builtin_amdgcn_perm(a[j + 1], a[j], 0x05040100u);
+            phi[j] = __builtin_amdgcn_perm(a[j + 1], a[j], 0x07060302u);
+        }
+        const uint32_t K01 = 8u | (28u << 16), K23 = 56u | (72u << 16), K45 = 56u | (28u << 16), K6 = 8u;
+#pragma unroll
+        for (int o = 0; o < CG; ++o) {
+            uint32_t lo = udot2(plo[o], K01, 32768u), hi = udot2(phi[o], K01, 32768u);
+            lo = udot2(plo[o + 2], K23, lo);
+            hi = udot2(phi[o + 2], K23, hi);
+            lo = udot2(plo[o + 4], K45, lo);
+            hi = udot2(phi[o + 4], K45, hi);
+            lo = udot2(a[o + 6], K6, lo);            // low half = left pixel of row o+6
+            hi = udot2(a[o + 6], K6 << 16, hi);      // high half = right pixel
+            ((uint16_t*)&s_sm[k][jr0 + o][0])[d] = (uint16_t)((lo >> 16) | ((hi >> 16) << 8));
+        }
     }
-    __syncthreads();
+    QSTAMP(7)
+    QSTAMP_WAVES(24)
+    lds_barrier();
     if (!interior) { // replicate the smoothed image outwards: Sobel runs with BORDER_REPLICATE
         uint8_t* sm = (uint8_t*)&s_sm[0][0][0];
         for (int it = tid; it < CH * QM_R * QH_W; it += QN) {
@@ -329,113 +438,114 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
                 if (rr >= 0 && rr < QM_R && cc >= 0 && cc < QH_W) sm[(k * QM_R + jr) * QH_W + x] = sm[(k * QM_R + rr) * QH_W + cc];
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 
-    // ---- D: Sobel + magnitude + orientation bin; q row qr <-> image row R0-1+qr <-> s_sm row qr+1 ----
+    QSTAMP(4)
+    // ---- D: Sobel + magnitude + orientation; q row qr <-> image row R0-1+qr <-> s_sm row qr+1.
+    //         Two pixels per dword (16-bit lanes): column sums / differences of the 3x3 window with packed adds,
+    //         (gx, gy) of one pixel in one dword so that gx^2 + gy^2 is a single v_dot2_i32_i16. ----
+    // mag is an integer < 2^24, so `mag > thr` (float, line2Dup.cpp:241) is `mag > floor(thr)` in integers
+    const int thr_i = (thr_sq < 2147483000.f) ? (int)floorf(thr_sq) : 0x7fffffff;
     for (int it = tid; it < QQ_R * (QH_W / 4); it += QN) {
         const int qr = it / (QH_W / 4), g = it - qr * (QH_W / 4);
         const int gm = g > 0 ? g - 1 : 0, gp = g < QH_W / 4 - 1 ? g + 1 : g;
-        int bx[4] = {0, 0, 0, 0}, by[4] = {0, 0, 0, 0}, bm[4] = {-1, -1, -1, -1};
+        uint32_t bv[4] = {0, 0, 0, 0}; // (gx, gy) of the strongest channel so far
+        int bm[4] = {-1, -1, -1, -1};
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-            int p[3][6]; // rows jr-1, jr, jr+1; columns x-1 .. x+4
+            // columns x-1 .. x+4 of rows qr-1 .. qr+1 as three u16 pairs per row
+            uint32_t X[3], Y[3], Z[3];
 #pragma unroll
             for (int rw = 0; rw < 3; ++rw) {
                 const uint32_t dl = s_sm[k][qr + rw][gm], dc = s_sm[k][qr + rw][g], dr = s_sm[k][qr + rw][gp];
-                p[rw][0] = (int)(dl >> 24);
-                p[rw][1] = (int)(dc & 0xff);
-                p[rw][2] = (int)((dc >> 8) & 0xff);
-                p[rw][3] = (int)((dc >> 16) & 0xff);
-                p[rw][4] = (int)(dc >> 24);
-                p[rw][5] = (int)(dr & 0xff);
+                X[rw] = __builtin_amdgcn_perm(dc, dl, 0x0c040c03u); // (x-1, x)
+                Y[rw] = __builtin_amdgcn_perm(dc, dc, 0x0c020c01u); // (x+1, x+2)
+                Z[rw] = __builtin_amdgcn_perm(dr, dc, 0x0c040c03u); // (x+3, x+4)
             }
-            int cw[6], dd[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                cw[c] = p[0][c] + 2 * p[1][c] + p[2][c];
-                dd[c] = p[2][c] - p[0][c];
-            }
+            const uint32_t cwX = pk_add(pk_2a_plus_b(X[1], X[0]), X[2]), ddX = pk_sub(X[2], X[0]);
+            const uint32_t cwY = pk_add(pk_2a_plus_b(Y[1], Y[0]), Y[2]), ddY = pk_sub(Y[2], Y[0]);
+            const uint32_t cwZ = pk_add(pk_2a_plus_b(Z[1], Z[0]), Z[2]), ddZ = pk_sub(Z[2], Z[0]);
+            const uint32_t gx01 = pk_sub(cwY, cwX), gx23 = pk_sub(cwZ, cwY);
+            const uint32_t gy01 = pk_add(pk_2a_plus_b(__builtin_amdgcn_alignbit(ddY, ddX, 16), ddX), ddY);
+            const uint32_t gy23 = pk_add(pk_2a_plus_b(__builtin_amdgcn_alignbit(ddZ, ddY, 16), ddY), ddZ);
+            uint32_t v[4];
+            v[0] = __builtin_amdgcn_perm(gy01, gx01, 0x05040100u);
+            v[1] = __builtin_amdgcn_perm(gy01, gx01, 0x07060302u);
+            v[2] = __builtin_amdgcn_perm(gy23, gx23, 0x05040100u);
+            v[3] = __builtin_amdgcn_perm(gy23, gx23, 0x07060302u);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int gx = cw[m + 2] - cw[m];
-                const int gy = dd[m] + 2 * dd[m + 1] + dd[m + 2];
-                const int mg = gx * gx + gy * gy;
+                const int mg = sdot2(v[m], v[m], 0);
                 if (mg > bm[m]) { // maximum magnitude, ties to the lower channel (:370-387)
                     bm[m] = mg;
-                    bx[m] = gx;
-                    by[m] = gy;
+                    bv[m] = v[m];
                 }
             }
         }
-        uint32_t codes = 0;
+        uint32_t words[4], strong = 0;
         const int r = R0 - 1 + qr;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int c = C0 - 4 + 4 * g + m;
-            uint32_t code = 0;
-            if (r >= 0 && r < rows && c >= 0 && c < cols) {
-                const float mag = (float)bm[m];
-                float ang = 0.f;
-                int q16;
-                if (WITH_FLOAT) { // the unquantised angle is an output here: the float pipeline itself
-                    ang = fast_atan2_deg((float)by[m], (float)bx[m]);
-                    q16 = __float2int_rn(__fmul_rn(ang, (float)(16.0 / 360.0)));
-                    q16 = q16 < 0 ? 0 : (q16 > 255 ? 255 : q16);
-                } else {
-                    q16 = orientation_bin16(bx[m], by[m]);
+            uint32_t w;
+            if (WITH_FLOAT) { // the unquantised angle is an output here: the float pipeline itself
+                const int gx = (int)(short)(bv[m] & 0xffffu), gy = (int)bv[m] >> 16;
+                const float ang = fast_atan2_deg((float)gy, (float)gx);
+                int q16 = __float2int_rn(__fmul_rn(ang, (float)(16.0 / 360.0)));
+                q16 = q16 < 0 ? 0 : (q16 > 255 ? 255 : q16);
+                w = 1u << (4 * (q16 & 7));
+                if (r >= 0 && r < rows && c >= 0 && c < cols && qr >= 1 && qr <= QT_R && c >= C0 && c < C0 + QT_C) {
+                    if (mag_out) mag_out[(size_t)r * cols + c] = (float)bm[m];
+                    if (ori_out) ori_out[(size_t)r * cols + c] = ang;
                 }
-                const bool ring = (r == 0) || (r == rows - 1) || (c == 0) || (c == cols - 1);
-                code = (uint32_t)(ring ? 0 : (q16 & 7)) | ((mag > thr_sq) ? 8u : 0u);
-                if (WITH_FLOAT) {
-                    if (qr >= 1 && qr <= QT_R && c >= C0 && c < C0 + QT_C) {
-                        if (mag_out) mag_out[(size_t)r * cols + c] = mag;
-                        if (ori_out) ori_out[(size_t)r * cols + c] = ang;
-                    }
-                }
+            } else {
+                w = vote_word(bv[m]);
             }
-            codes |= code << (8 * m);
+            uint32_t st = bm[m] > thr_i ? 0x80u : 0u;
+            if (!interior) { // pixels outside the image and the 1-pixel ring (:232-238) vote for bin 0
+                const bool inside = r >= 0 && r < rows && c >= 0 && c < cols;
+                const bool ring = (r == 0) || (r == rows - 1) || (c == 0) || (c == cols - 1);
+                if (!inside || ring) w = 1u;
+                if (!inside) st = 0;
+            }
+            words[m] = w;
+            strong |= st << (8 * m);
         }
-        s_q[qr][g] = codes;
+        *(uint4*)&s_w[qr][4 * g] = make_uint4(words[0], words[1], words[2], words[3]);
+        s_st[qr][g] = strong;
     }
-    __syncthreads();
+    lds_barrier();
+    QSTAMP(5)
 
-    // ---- E: 3x3 majority vote (>= 5 of 9); out cols C0+4g .. +3 <-> q columns 4(g+1) .. +3 ----
+    // ---- E: 3x3 majority vote (>= 5 of 9) around strong pixels: the nine vote words add up to eight 4-bit
+    //         counters; out cols C0+4g .. +3 <-> q columns 4(g+1) .. +3 ----
     if (tid < 256) {
         const int er = tid >> 4, g = tid & 15;
         const int r = R0 + er;
         if (r < rows) {
-            uint32_t nb[3][3];
-#pragma unroll
-            for (int rw = 0; rw < 3; ++rw) {
-                nb[rw][0] = s_q[er + rw][g];
-                nb[rw][1] = s_q[er + rw][g + 1];
-                nb[rw][2] = s_q[er + rw][g + 2];
-            }
-            const uint32_t centre = nb[1][1];
+            const uint32_t centre = s_st[er + 1][g + 1];
             uint32_t packed = 0;
-            if (centre & 0x08080808u) {
+            if (centre) {
+                uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int rw = 0; rw < 3; ++rw) {
+                    const uint32_t w0 = s_w[er + rw][4 * g + 3];
+                    const uint4 wc = *(const uint4*)&s_w[er + rw][4 * g + 4];
+                    const uint32_t w5 = s_w[er + rw][4 * g + 8];
+                    acc[0] += w0 + wc.x + wc.y;
+                    acc[1] += wc.x + wc.y + wc.z;
+                    acc[2] += wc.y + wc.z + wc.w;
+                    acc[3] += wc.z + wc.w + w5;
+                }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const int c = C0 + 4 * g + m;
-                    if (!((centre >> (8 * m)) & 8u)) continue;
-                    if (!(c < cols && r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1)) continue;
-                    uint32_t h = 0; // eight 4-bit vote counters
-#pragma unroll
-                    for (int rw = 0; rw < 3; ++rw) {
-                        // columns m-1, m, m+1 relative to the centre dword
-                        const uint32_t left = m == 0 ? (nb[rw][0] >> 24) : (nb[rw][1] >> (8 * (m - 1)));
-                        const uint32_t mid = nb[rw][1] >> (8 * m);
-                        const uint32_t right = m == 3 ? nb[rw][2] : (nb[rw][1] >> (8 * (m + 1)));
-                        h += 1u << (4 * (left & 7));
-                        h += 1u << (4 * (mid & 7));
-                        h += 1u << (4 * (right & 7));
-                    }
-                    uint32_t v = 0;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (((h >> (4 * i)) & 15u) >= 5u) v = 1u << i;
-                    if (mask && !mask[(size_t)r * cols + c]) v = 0;
+                    const uint32_t hit = (acc[m] + 0x33333333u) & 0x88888888u; // counters >= 5 (at most one)
+                    bool on = hit != 0 && ((centre >> (8 * m)) & 0xffu) != 0;
+                    if (!interior) on = on && c < cols && r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1;
+                    uint32_t v = on ? 1u << (__builtin_ctz(hit) >> 2) : 0u;
+                    if (mask && v && !mask[(size_t)r * cols + c]) v = 0;
                     packed |= v << (8 * m);
                 }
             }
@@ -448,6 +558,7 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
             }
         }
     }
+    QSTAMP(6)
 }
 
 // cv::pyrDown: [1 4 6 4 1]^2, (sum + 128) >> 8, REFLECT_101; dst = (rows/2, cols/2).
