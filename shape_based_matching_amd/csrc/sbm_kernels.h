@@ -162,7 +162,7 @@ __device__ unsigned long long* g_qstamp = nullptr;
 #endif
 #define QSTAMP(i)                                                                               \
     if (QSTAMP_ON(i) && threadIdx.x == 0 && g_qstamp) {                                         \
-        unsigned long long* q_ = g_qstamp + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 48; \
+        unsigned long long* q_ = g_qstamp + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64; \
         if (i == 0 || i == 6) q_[i] = __builtin_amdgcn_s_memrealtime();                         \
         q_[8 + i] = __builtin_amdgcn_s_memtime();                                               \
         if (i == 0) {                                                                           \
@@ -172,7 +172,7 @@ __device__ unsigned long long* g_qstamp = nullptr;
     }
 #define QSTAMP_WAVES(base)                                        \
     if (QSTAMP_ON(1) && (threadIdx.x & 63) == 0 && g_qstamp)      \
-        g_qstamp[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 48 + (base) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime();
+        g_qstamp[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + (base) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime();
 #else
 #define QSTAMP(i)
 #define QSTAMP_WAVES(base)
@@ -242,25 +242,38 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
     const int R0 = blockIdx.y * QT_R, C0 = blockIdx.x * QT_C;
     const bool interior = R0 >= 5 && R0 + QT_R + 5 <= rows && C0 >= 8 && C0 + QT_C + 8 <= cols;
     QSTAMP(0)
+    // every kernel argument is fetched here, with the first ones: a scalar load issued in the middle of the
+    // tile costs a scalar-cache round trip on the critical path of its phase
+    asm volatile("" ::"s"(thr_sq), "s"(out), "s"(mask), "s"(pyr_out), "s"(mag_out), "s"(ori_out), "s"(stride));
     if (tid == 0) s_nonflat = 0;
 
     // ---- A: source tile -> planar LDS (rows clamped; a 4-pixel group that sticks out of the image
     //         left or right takes the per-byte clamped path = BORDER_REPLICATE) ----
+    const bool whole_groups = cols >= 4 && (cols & 3) == 0; // 4-pixel groups lie entirely inside or outside the image
     for (int it = tid; it < QS_R * (QS_W / 4); it += QN) {
         const int r = it / (QS_W / 4), g = it - r * (QS_W / 4);
         const int gr = clampi(R0 - 5 + r, 0, rows - 1);
         const int c = C0 - 8 + 4 * g;
         const uint8_t* rowp = img + (size_t)gr * stride;
-        if (c >= 0 && c + 4 <= cols) {
-            const uint8_t* p = rowp + (size_t)c * CH;
+        if (whole_groups) {
+            // a group outside the image replicates the first / last pixel of the row: load the nearest inside
+            // group and broadcast its edge byte (one memory round trip for every lane, no divergent byte path)
+            const uint8_t* p = rowp + (size_t)clampi(c, 0, cols - 4) * CH;
+            uint32_t w[CH];
             if (CH == 1) {
-                s_src[0][r][g] = ld_u32_any(p);
+                w[0] = ld_u32_any(p);
             } else {
                 const uint32_t d0 = ld_u32_any(p), d1 = ld_u32_any(p + 4), d2 = ld_u32_any(p + 8);
                 // 12 interleaved bytes b0..b11 -> channel k = {b[k], b[k+3], b[k+6], b[k+9]}
-                s_src[0][r][g] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c060300u), 0x05020100u);
-                s_src[1 % CH][r][g] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c070401u), 0x06020100u);
-                s_src[2 % CH][r][g] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c0c0502u), 0x07040100u);
+                w[0] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c060300u), 0x05020100u);
+                w[1 % CH] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c070401u), 0x06020100u);
+                w[2 % CH] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c0c0502u), 0x07040100u);
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                if (c < 0) w[k] = (w[k] & 0xffu) * 0x01010101u;
+                if (c >= cols) w[k] = (w[k] >> 24) * 0x01010101u;
+                s_src[k][r][g] = w[k];
             }
         } else {
 #pragma unroll
@@ -275,61 +288,11 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
     lds_barrier();
     QSTAMP(1)
 
-    // ---- P: pyrDown of this tile (8 x 32 outputs), REFLECT_101 at the image border ----
-    if (pyr_out && tid < 256) {
-        const int yy = tid >> 5, xx = tid & 31;
-        const int oy = (R0 >> 1) + yy, ox = (C0 >> 1) + xx;
-        const int drows = rows >> 1, dcols = cols >> 1;
-        if (oy < drows && ox < dcols) {
-            const bool inner = 2 * oy >= 2 && 2 * oy + 2 < rows && 2 * ox >= 2 && 2 * ox + 2 < cols;
-            int accs[CH];
-            if (inner) { // taps are 5 consecutive bytes of 5 consecutive tile rows: v_dot4 + 1
-                const int r0t = 2 * yy + 3;      // tile row of image row 2*oy - 2
-                const int b0 = 2 * xx + 6;       // tile byte column of image col 2*ox - 2 (even: shift 0 or 2)
-                const int w = b0 >> 2, sh = b0 & 3;
-                const int K5[5] = {1, 4, 6, 4, 1};
-#pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    int acc = 0;
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) {
-                        const uint32_t d0 = s_src[k][r0t + j][w], d1 = s_src[k][r0t + j][w + 1];
-                        const uint32_t lo4 = __builtin_amdgcn_alignbyte(d1, d0, sh);
-                        const uint32_t b4 = (d1 >> (8 * sh)) & 0xffu;
-                        acc += K5[j] * (int)(__builtin_amdgcn_udot4(lo4, 0x04060401u, b4, false));
-                    }
-                    accs[k] = acc;
-                }
-            } else {
-                int ri[5], ci[5];
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    ri[j] = reflect101(2 * oy + j - 2, rows) - (R0 - 5);
-                    ci[j] = reflect101(2 * ox + j - 2, cols) - (C0 - 8);
-                }
-                const int K5[5] = {1, 4, 6, 4, 1};
-#pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    const uint8_t* sb = (const uint8_t*)&s_src[k][0][0];
-                    int acc = 0;
-                    for (int j = 0; j < 5; ++j) {
-                        int h = 0;
-                        for (int i = 0; i < 5; ++i) h += K5[i] * sb[ri[j] * QS_W + ci[i]];
-                        acc += K5[j] * h;
-                    }
-                    accs[k] = acc;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < CH; ++k) ((uint8_t*)&s_pyr[yy][0])[xx * CH + k] = (uint8_t)((accs[k] + 128) >> 8);
-        }
-    }
-
     // ---- flat-tile shortcut: if every channel of the source tile is constant, every gradient is 0,
     //      no pixel passes `mag > weak^2` and the whole output tile is 0 (padding / saturated background:
-    //      the reference's own demo pads the frame with 250 black pixels, test.cpp:344-347).
-    //      WITH_FLOAT keeps the full path so that magnitude / angle are written everywhere. ----
-    bool tile_flat = false;
+    //      the reference's own demo pads the frame with 250 black pixels, test.cpp:344-347); the pyrDown of
+    //      a constant tile is the same constant.  WITH_FLOAT keeps the full path so that magnitude / angle
+    //      are written everywhere. ----
     if (!WITH_FLOAT && thr_sq >= 0.f) {
         bool flat = true;
 #pragma unroll
@@ -338,59 +301,120 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
             for (int it = tid; it < QS_R * (QS_W / 4); it += QN) flat = flat && (s_src[k][it / (QS_W / 4)][it % (QS_W / 4)] == ref);
         }
         if (!flat) s_nonflat = 1; // benign race: every writer stores the same value
-        tile_flat = true;
-    }
-    if (pyr_out || tile_flat) lds_barrier();
-    if (tile_flat) tile_flat = s_nonflat == 0;
-    // the tile of the next pyramid level leaves as dwords (row segments of 32 * CH bytes)
-    if (pyr_out && tid < (QT_R / 2) * (QT_C / 2 * CH / 4)) {
-        const int yy = tid / (QT_C / 2 * CH / 4), w = tid - yy * (QT_C / 2 * CH / 4);
-        const int oy = (R0 >> 1) + yy, drows = rows >> 1, dcols = cols >> 1;
-        const int b0 = (C0 >> 1) * CH + 4 * w; // byte column in the destination row
-        if (oy < drows && b0 < dcols * CH) {
-            uint8_t* o = pyr_out + (size_t)oy * dcols * CH + b0;
-            const uint32_t v = s_pyr[yy][w];
-            if (b0 + 4 <= dcols * CH && (((uintptr_t)o) & 3) == 0) {
-                *(uint32_t*)o = v;
-            } else {
-                for (int m = 0; m < 4; ++m)
-                    if (b0 + m < dcols * CH) o[m] = (uint8_t)(v >> (8 * m));
+        lds_barrier();
+        if (s_nonflat == 0) {
+            const int er = tid >> 4, g = tid & 15;
+            const int r = R0 + er;
+            if (tid < 256 && r < rows) {
+                uint8_t* o = out + (size_t)r * cols + C0 + 4 * g;
+                if (C0 + 4 * g + 3 < cols && ((((size_t)r * cols + C0 + 4 * g) & 3) == 0)) {
+                    *(uint32_t*)o = 0;
+                } else {
+                    for (int m = 0; m < 4; ++m)
+                        if (C0 + 4 * g + m < cols) o[m] = 0;
+                }
             }
+            const int ps = tid - 256;
+            if (pyr_out && ps >= 0 && ps < (QT_R / 2) * (QT_C / 2 * CH / 4)) {
+                const int yy = ps / (QT_C / 2 * CH / 4), w = ps - yy * (QT_C / 2 * CH / 4);
+                const int oy = (R0 >> 1) + yy, drows = rows >> 1, dcols = cols >> 1;
+                const int b0 = (C0 >> 1) * CH + 4 * w; // byte column in the destination row (a multiple of CH at w = 0)
+                if (oy < drows && b0 < dcols * CH) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) v |= (s_src[(4 * w + m) % CH][0][0] & 0xffu) << (8 * m);
+                    uint8_t* o = pyr_out + (size_t)oy * dcols * CH + b0;
+                    if (b0 + 4 <= dcols * CH && (((uintptr_t)o) & 3) == 0) {
+                        *(uint32_t*)o = v;
+                    } else {
+                        for (int m = 0; m < 4; ++m)
+                            if (b0 + m < dcols * CH) o[m] = (uint8_t)(v >> (8 * m));
+                    }
+                }
+            }
+            return;
         }
     }
-    if (tile_flat) {
-        const int er = tid >> 4, g = tid & 15;
-        const int r = R0 + er;
-        if (tid < 256 && r < rows) {
-            uint8_t* o = out + (size_t)r * cols + C0 + 4 * g;
-            if (C0 + 4 * g + 3 < cols && ((((size_t)r * cols + C0 + 4 * g) & 3) == 0)) {
-                *(uint32_t*)o = 0;
-            } else {
-                for (int m = 0; m < 4; ++m)
-                    if (C0 + 4 * g + m < cols) o[m] = 0;
-            }
-        }
-        return;
-    }
-
     QSTAMP(2)
+
+    // The last 256 threads compute cv::pyrDown of the tile (8 x 32 outputs, REFLECT_101 at the image border:
+    // the next pyramid level's source image) while the others run the two Gaussian passes: channel 0 beside
+    // the horizontal pass, the remaining channels beside the vertical pass.
+    const int nwork = pyr_out ? QN - 256 : QN; // threads of the Gaussian passes
+    auto pyr_channels = [&](int k0, int k1) {
+        const int pw = tid - (QN - 256);
+        const int yy = pw >> 5, xx = pw & 31;
+        const int oy = (R0 >> 1) + yy, ox = (C0 >> 1) + xx;
+        const int drows = rows >> 1, dcols = cols >> 1;
+        if (oy >= drows || ox >= dcols) return;
+        if (rows >= 4 && cols >= 4) {
+            // taps are 5 consecutive bytes of 5 consecutive tile rows: v_dot4 + 1.  REFLECT_101 touches only the
+            // taps -2, -1 of the first output row / column (they fold onto +2, +1) and the tap +2 of the last one
+            // when the extent is even (it folds onto the centre): per-lane weights, no divergent border path.
+            const int r0t = 2 * yy + 3; // tile row of image row 2*oy - 2
+            const int b0 = 2 * xx + 6;  // tile byte column of image col 2*ox - 2 (even: shift 0 or 2)
+            const int w = b0 >> 2, sh = b0 & 3;
+            uint32_t wlo = 0x04060401u, w4 = 1u; // weights of window bytes 0..3 and of byte 4
+            if (ox == 0) wlo = 0x08060000u, w4 = 2u;
+            else if (2 * ox + 2 >= cols) wlo = 0x04070401u, w4 = 0u;
+            uint32_t wr[5] = {1u, 4u, 6u, 4u, 1u};
+            if (oy == 0) wr[0] = 0u, wr[1] = 0u, wr[3] = 8u, wr[4] = 2u;
+            else if (2 * oy + 2 >= rows) wr[2] = 7u, wr[4] = 0u;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                if (k < k0 || k >= k1) continue;
+                uint32_t acc = 128u;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const uint32_t d0 = s_src[k][r0t + j][w], d1 = s_src[k][r0t + j][w + 1];
+                    const uint32_t lo4 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                    const uint32_t b4 = (d1 >> (8 * sh)) & 0xffu;
+                    acc += wr[j] * __builtin_amdgcn_udot4(lo4, wlo, b4 * w4, false);
+                }
+                ((uint8_t*)&s_pyr[yy][0])[xx * CH + k] = (uint8_t)(acc >> 8);
+            }
+        } else { // degenerate extents: the literal reflect loop
+            const int K5[5] = {1, 4, 6, 4, 1};
+            int ri[5], ci[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                ri[j] = reflect101(2 * oy + j - 2, rows) - (R0 - 5);
+                ci[j] = reflect101(2 * ox + j - 2, cols) - (C0 - 8);
+            }
+            for (int k = k0; k < k1; ++k) {
+                const uint8_t* sb = (const uint8_t*)&s_src[k][0][0];
+                int acc = 0;
+                for (int j = 0; j < 5; ++j) {
+                    int h = 0;
+                    for (int i = 0; i < 5; ++i) h += K5[i] * sb[ri[j] * QS_W + ci[i]];
+                    acc += K5[j] * h;
+                }
+                ((uint8_t*)&s_pyr[yy][0])[xx * CH + k] = (uint8_t)((acc + 128) >> 8);
+            }
+        }
+    };
+
     // ---- B: horizontal 7-tap: output x (image col C0-4+x) reads source bytes x+1 .. x+7 ----
-    for (int it = tid; it < CH * QS_R * (QH_W / 4); it += QN) {
-        const int k = it / (QS_R * (QH_W / 4)), rem = it - k * (QS_R * (QH_W / 4));
-        const int r = rem / (QH_W / 4), g = rem - r * (QH_W / 4);
-        const uint32_t d0 = s_src[k][r][g], d1 = s_src[k][r][g + 1], d2 = s_src[k][r][g + 2];
-        const uint32_t KLO = 0x48381C08u; // 8, 28, 56, 72
-        const uint32_t KHI = 0x00081C38u; // 56, 28, 8, 0
-        uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KLO, 0u, false);
-        h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KHI, h0, false);
-        uint32_t h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KLO, 0u, false);
-        h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KHI, h1, false);
-        uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KLO, 0u, false);
-        h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KHI, h2, false);
-        uint32_t h3 = __builtin_amdgcn_udot4(d1, KLO, 0u, false);
-        h3 = __builtin_amdgcn_udot4(d2, KHI, h3, false);
-        s_h[k][r][2 * g] = h0 | (h1 << 16);
-        s_h[k][r][2 * g + 1] = h2 | (h3 << 16);
+    if (tid >= nwork) {
+        pyr_channels(0, 1);
+    } else {
+        for (int it = tid; it < CH * QS_R * (QH_W / 4); it += nwork) {
+            const int k = it / (QS_R * (QH_W / 4)), rem = it - k * (QS_R * (QH_W / 4));
+            const int r = rem / (QH_W / 4), g = rem - r * (QH_W / 4);
+            const uint32_t d0 = s_src[k][r][g], d1 = s_src[k][r][g + 1], d2 = s_src[k][r][g + 2];
+            const uint32_t KLO = 0x48381C08u; // 8, 28, 56, 72
+            const uint32_t KHI = 0x00081C38u; // 56, 28, 8, 0
+            uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KLO, 0u, false);
+            h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KHI, h0, false);
+            uint32_t h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KLO, 0u, false);
+            h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KHI, h1, false);
+            uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KLO, 0u, false);
+            h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KHI, h2, false);
+            uint32_t h3 = __builtin_amdgcn_udot4(d1, KLO, 0u, false);
+            h3 = __builtin_amdgcn_udot4(d2, KHI, h3, false);
+            s_h[k][r][2 * g] = h0 | (h1 << 16);
+            s_h[k][r][2 * g + 1] = h2 | (h3 << 16);
+        }
     }
     lds_barrier();
     QSTAMP(3)
@@ -399,7 +423,8 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
     //         output rows, so the CG+6 source rows and the (row j, row j+1) pairings are shared ----
     constexpr int CG = 5;
     static_assert(QM_R % CG == 0, "row groups tile the smoothed rows");
-    for (int it = tid; it < CH * (QM_R / CG) * (QH_W / 2); it += QN) {
+    if (tid >= nwork) pyr_channels(1, CH);
+    for (int it = tid; it < CH * (QM_R / CG) * (QH_W / 2) && tid < nwork; it += nwork) {
         const int kg = it / (QH_W / 2), d = it - kg * (QH_W / 2);
         const int k = kg / (QM_R / CG), jr0 = (kg - k * (QM_R / CG)) * CG;
         uint32_t a[CG + 6];
@@ -426,22 +451,52 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
     }
     QSTAMP(7)
     QSTAMP_WAVES(24)
+#if defined(SBM_QSTAMP) && !defined(SBM_QSTAMP_LIGHT)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // split the barrier: LDS drain, then arrival
+    QSTAMP_WAVES(40)
+#endif
     lds_barrier();
     if (!interior) { // replicate the smoothed image outwards: Sobel runs with BORDER_REPLICATE
-        uint8_t* sm = (uint8_t*)&s_sm[0][0][0];
-        for (int it = tid; it < CH * QM_R * QH_W; it += QN) {
-            const int k = it / (QM_R * QH_W), rem = it - k * (QM_R * QH_W);
-            const int jr = rem / QH_W, x = rem - jr * QH_W;
-            const int r = R0 - 2 + jr, c = C0 - 4 + x;
-            if (r < 0 || r >= rows || c < 0 || c >= cols) {
-                const int rr = clampi(r, 0, rows - 1) - (R0 - 2), cc = clampi(c, 0, cols - 1) - (C0 - 4);
-                if (rr >= 0 && rr < QM_R && cc >= 0 && cc < QH_W) sm[(k * QM_R + jr) * QH_W + x] = sm[(k * QM_R + rr) * QH_W + cc];
+        // one dword (4 pixels) per item; sources are in-image positions, which no item writes
+        for (int it = tid; it < CH * QM_R * (QH_W / 4); it += QN) {
+            const int k = it / (QM_R * (QH_W / 4)), rem = it - k * (QM_R * (QH_W / 4));
+            const int jr = rem / (QH_W / 4), g = rem - jr * (QH_W / 4);
+            const int r = R0 - 2 + jr, c0 = C0 - 4 + 4 * g;
+            const bool col_in = c0 >= 0 && c0 + 4 <= cols;
+            if (r >= 0 && r < rows && col_in) continue;
+            const int jrc = clampi(clampi(r, 0, rows - 1) - (R0 - 2), 0, QM_R - 1);
+            uint32_t v;
+            if (col_in) {
+                v = s_sm[k][jrc][g];
+            } else {
+                const uint8_t* srow = (const uint8_t*)&s_sm[k][jrc][0];
+                v = 0;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) v |= (uint32_t)srow[clampi(clampi(c0 + m, 0, cols - 1) - (C0 - 4), 0, QH_W - 1)] << (8 * m);
             }
+            s_sm[k][jr][g] = v;
         }
         lds_barrier();
     }
 
     QSTAMP(4)
+    // the tile of the next pyramid level leaves as dwords (row segments of 32 * CH bytes), beside phase D
+    if (pyr_out && tid >= QN - (QT_R / 2) * (QT_C / 2 * CH / 4)) {
+        const int ps = tid - (QN - (QT_R / 2) * (QT_C / 2 * CH / 4));
+        const int yy = ps / (QT_C / 2 * CH / 4), w = ps - yy * (QT_C / 2 * CH / 4);
+        const int oy = (R0 >> 1) + yy, drows = rows >> 1, dcols = cols >> 1;
+        const int b0 = (C0 >> 1) * CH + 4 * w; // byte column in the destination row
+        if (oy < drows && b0 < dcols * CH) {
+            uint8_t* o = pyr_out + (size_t)oy * dcols * CH + b0;
+            const uint32_t v = s_pyr[yy][w];
+            if (b0 + 4 <= dcols * CH && (((uintptr_t)o) & 3) == 0) {
+                *(uint32_t*)o = v;
+            } else {
+                for (int m = 0; m < 4; ++m)
+                    if (b0 + m < dcols * CH) o[m] = (uint8_t)(v >> (8 * m));
+            }
+        }
+    }
     // ---- D: Sobel + magnitude + orientation; q row qr <-> image row R0-1+qr <-> s_sm row qr+1.
     //         Two pixels per dword (16-bit lanes): column sums / differences of the 3x3 window with packed adds,
     //         (gx, gy) of one pixel in one dword so that gx^2 + gy^2 is a single v_dot2_i32_i16. ----

@@ -7,7 +7,7 @@
 #include <map>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
-constexpr int NT = 8;
+constexpr int NT = 10;
 __global__ __launch_bounds__(256) void k_probe(unsigned long long* out, int iters)
 {
     __shared__ uint32_t lds[4096];
@@ -40,6 +40,17 @@ __global__ __launch_bounds__(256) void k_probe(unsigned long long* out, int iter
     t[7] = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; ++i) { a = a * 6 + b; b = b * 4 + c; c = (c * a) + 1; }
     t[8] = __builtin_amdgcn_s_memtime();
+    { // dependent s_memtime reads: latency of the SMEM time path
+        unsigned long long x = t[8];
+        for (int i = 0; i < 32; ++i) { unsigned long long y = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); x += y & 1; }
+        a += (uint32_t)x;
+        t[9] = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 32; ++i) { unsigned long long y = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); x += y & 1; }
+        a += (uint32_t)x;
+        t[10] = __builtin_amdgcn_s_memtime();
+        t[9] = t[8] + (t[9] - t[8]) * (unsigned long long)iters / 32;   // scaled so that the /iters below gives per-read cycles
+        t[10] = t[9] + (t[10] - (t[8] + (t[9] - t[8]) * 32 / (unsigned long long)iters)) * (unsigned long long)iters / 32;
+    }
     if (a + b + c == 0x12345678u) lds[0] = a;
     if (tid == 0) {
         unsigned long long* o = out + (size_t)blockIdx.x * (NT + 2);
@@ -56,7 +67,7 @@ int main()
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h((size_t)nb * (NT + 2));
     CK(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
-    const char* names[NT] = {"valu", "dot4", "perm", "ldsrd", "ldswr16/8", "barrier", "lds+perm+dot2", "mul"};
+    const char* names[NT] = {"valu", "dot4", "perm", "ldsrd", "ldswr16/8", "barrier", "lds+perm+dot2", "mul", "s_memtime", "s_memrealtime"};
     std::map<int, std::vector<std::vector<double>>> se;
     for (int b = 0; b < nb; ++b) {
         const unsigned long long* o = &h[(size_t)b * (NT + 2)];
