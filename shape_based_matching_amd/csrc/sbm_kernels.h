@@ -498,39 +498,39 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
         }
     }
     // ---- D: Sobel + magnitude + orientation; q row qr <-> image row R0-1+qr <-> s_sm row qr+1.
-    //         Two pixels per dword (16-bit lanes): column sums / differences of the 3x3 window with packed adds,
-    //         (gx, gy) of one pixel in one dword so that gx^2 + gy^2 is a single v_dot2_i32_i16. ----
+    //         An item = two adjacent pixels (x, x+1), held as the two 16-bit lanes of a dword: column sums /
+    //         differences of the 3x3 window with packed adds, then (gx, gy) of one pixel in one dword so that
+    //         gx^2 + gy^2 is a single v_dot2_i32_i16. ----
     // mag is an integer < 2^24, so `mag > thr` (float, line2Dup.cpp:241) is `mag > floor(thr)` in integers
     const int thr_i = (thr_sq < 2147483000.f) ? (int)floorf(thr_sq) : 0x7fffffff;
-    for (int it = tid; it < QQ_R * (QH_W / 4); it += QN) {
-        const int qr = it / (QH_W / 4), g = it - qr * (QH_W / 4);
-        const int gm = g > 0 ? g - 1 : 0, gp = g < QH_W / 4 - 1 ? g + 1 : g;
-        uint32_t bv[4] = {0, 0, 0, 0}; // (gx, gy) of the strongest channel so far
-        int bm[4] = {-1, -1, -1, -1};
+    for (int it = tid; it < QQ_R * (QH_W / 2); it += QN) {
+        const int qr = it / (QH_W / 2), j = it - qr * (QH_W / 2);
+        // the four columns x-1 .. x+2 sit in two consecutive dwords (lo, hi) of the smoothed row, at byte 3
+        // (x = 4g, 4g+1) or at byte 1 (x = 4g+2, 4g+3) of lo
+        const int g = j >> 1, odd = j & 1;
+        const int glo = odd ? g : (g > 0 ? g - 1 : 0), ghi = odd ? (g < QH_W / 4 - 1 ? g + 1 : g) : g;
+        const uint32_t selX = odd ? 0x0c020c01u : 0x0c040c03u; // (x-1, x)
+        const uint32_t selY = odd ? 0x0c040c03u : 0x0c060c05u; // (x+1, x+2)
+        uint32_t bv[2] = {0, 0}; // (gx, gy) of the strongest channel so far
+        int bm[2] = {-1, -1};
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-            // columns x-1 .. x+4 of rows qr-1 .. qr+1 as three u16 pairs per row
-            uint32_t X[3], Y[3], Z[3];
+            uint32_t X[3], Y[3];
 #pragma unroll
             for (int rw = 0; rw < 3; ++rw) {
-                const uint32_t dl = s_sm[k][qr + rw][gm], dc = s_sm[k][qr + rw][g], dr = s_sm[k][qr + rw][gp];
-                X[rw] = __builtin_amdgcn_perm(dc, dl, 0x0c040c03u); // (x-1, x)
-                Y[rw] = __builtin_amdgcn_perm(dc, dc, 0x0c020c01u); // (x+1, x+2)
-                Z[rw] = __builtin_amdgcn_perm(dr, dc, 0x0c040c03u); // (x+3, x+4)
+                const uint32_t lo = s_sm[k][qr + rw][glo], hi = s_sm[k][qr + rw][ghi];
+                X[rw] = __builtin_amdgcn_perm(hi, lo, selX);
+                Y[rw] = __builtin_amdgcn_perm(hi, lo, selY);
             }
             const uint32_t cwX = pk_add(pk_2a_plus_b(X[1], X[0]), X[2]), ddX = pk_sub(X[2], X[0]);
             const uint32_t cwY = pk_add(pk_2a_plus_b(Y[1], Y[0]), Y[2]), ddY = pk_sub(Y[2], Y[0]);
-            const uint32_t cwZ = pk_add(pk_2a_plus_b(Z[1], Z[0]), Z[2]), ddZ = pk_sub(Z[2], Z[0]);
-            const uint32_t gx01 = pk_sub(cwY, cwX), gx23 = pk_sub(cwZ, cwY);
-            const uint32_t gy01 = pk_add(pk_2a_plus_b(__builtin_amdgcn_alignbit(ddY, ddX, 16), ddX), ddY);
-            const uint32_t gy23 = pk_add(pk_2a_plus_b(__builtin_amdgcn_alignbit(ddZ, ddY, 16), ddY), ddZ);
-            uint32_t v[4];
-            v[0] = __builtin_amdgcn_perm(gy01, gx01, 0x05040100u);
-            v[1] = __builtin_amdgcn_perm(gy01, gx01, 0x07060302u);
-            v[2] = __builtin_amdgcn_perm(gy23, gx23, 0x05040100u);
-            v[3] = __builtin_amdgcn_perm(gy23, gx23, 0x07060302u);
+            const uint32_t gx = pk_sub(cwY, cwX);
+            const uint32_t gy = pk_add(pk_2a_plus_b(__builtin_amdgcn_alignbit(ddY, ddX, 16), ddX), ddY);
+            uint32_t v[2];
+            v[0] = __builtin_amdgcn_perm(gy, gx, 0x05040100u);
+            v[1] = __builtin_amdgcn_perm(gy, gx, 0x07060302u);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < 2; ++m) {
                 const int mg = sdot2(v[m], v[m], 0);
                 if (mg > bm[m]) { // maximum magnitude, ties to the lower channel (:370-387)
                     bm[m] = mg;
@@ -538,11 +538,11 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
                 }
             }
         }
-        uint32_t words[4], strong = 0;
+        uint32_t words[2], strong = 0;
         const int r = R0 - 1 + qr;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int c = C0 - 4 + 4 * g + m;
+        for (int m = 0; m < 2; ++m) {
+            const int c = C0 - 4 + 2 * j + m;
             uint32_t w;
             if (WITH_FLOAT) { // the unquantised angle is an output here: the float pipeline itself
                 const int gx = (int)(short)(bv[m] & 0xffffu), gy = (int)bv[m] >> 16;
@@ -567,36 +567,35 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
             words[m] = w;
             strong |= st << (8 * m);
         }
-        *(uint4*)&s_w[qr][4 * g] = make_uint4(words[0], words[1], words[2], words[3]);
-        s_st[qr][g] = strong;
+        *(uint2*)&s_w[qr][2 * j] = make_uint2(words[0], words[1]);
+        ((uint16_t*)&s_st[qr][0])[j] = (uint16_t)strong;
     }
     lds_barrier();
     QSTAMP(5)
 
     // ---- E: 3x3 majority vote (>= 5 of 9) around strong pixels: the nine vote words add up to eight 4-bit
-    //         counters; out cols C0+4g .. +3 <-> q columns 4(g+1) .. +3 ----
-    if (tid < 256) {
-        const int er = tid >> 4, g = tid & 15;
+    //         counters; an item = two output pixels, cols C0+2j, +1 <-> q columns 4+2j, 5+2j ----
+    if (tid < QT_R * (QT_C / 2)) {
+        const int er = tid >> 5, j = tid & 31;
         const int r = R0 + er;
         if (r < rows) {
-            const uint32_t centre = s_st[er + 1][g + 1];
+            const uint32_t centre = ((const uint16_t*)&s_st[er + 1][0])[2 + j];
             uint32_t packed = 0;
             if (centre) {
-                uint32_t acc[4] = {0, 0, 0, 0};
+                uint32_t acc0 = 0, acc1 = 0;
 #pragma unroll
                 for (int rw = 0; rw < 3; ++rw) {
-                    const uint32_t w0 = s_w[er + rw][4 * g + 3];
-                    const uint4 wc = *(const uint4*)&s_w[er + rw][4 * g + 4];
-                    const uint32_t w5 = s_w[er + rw][4 * g + 8];
-                    acc[0] += w0 + wc.x + wc.y;
-                    acc[1] += wc.x + wc.y + wc.z;
-                    acc[2] += wc.y + wc.z + wc.w;
-                    acc[3] += wc.z + wc.w + w5;
+                    const uint32_t w0 = s_w[er + rw][2 * j + 3];
+                    const uint2 wc = *(const uint2*)&s_w[er + rw][2 * j + 4];
+                    const uint32_t w3 = s_w[er + rw][2 * j + 6];
+                    const uint32_t mid = wc.x + wc.y;
+                    acc0 += w0 + mid;
+                    acc1 += mid + w3;
                 }
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int c = C0 + 4 * g + m;
-                    const uint32_t hit = (acc[m] + 0x33333333u) & 0x88888888u; // counters >= 5 (at most one)
+                for (int m = 0; m < 2; ++m) {
+                    const int c = C0 + 2 * j + m;
+                    const uint32_t hit = ((m ? acc1 : acc0) + 0x33333333u) & 0x88888888u; // counters >= 5 (at most one)
                     bool on = hit != 0 && ((centre >> (8 * m)) & 0xffu) != 0;
                     if (!interior) on = on && c < cols && r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1;
                     uint32_t v = on ? 1u << (__builtin_ctz(hit) >> 2) : 0u;
@@ -604,12 +603,12 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
                     packed |= v << (8 * m);
                 }
             }
-            uint8_t* o = out + (size_t)r * cols + C0 + 4 * g;
-            if (C0 + 4 * g + 3 < cols && ((((size_t)r * cols + C0 + 4 * g) & 3) == 0)) {
-                *(uint32_t*)o = packed;
+            uint8_t* o = out + (size_t)r * cols + C0 + 2 * j;
+            if (C0 + 2 * j + 1 < cols && (((uintptr_t)o) & 1) == 0) {
+                *(uint16_t*)o = (uint16_t)packed;
             } else {
-                for (int m = 0; m < 4; ++m)
-                    if (C0 + 4 * g + m < cols) o[m] = (uint8_t)(packed >> (8 * m));
+                for (int m = 0; m < 2; ++m)
+                    if (C0 + 2 * j + m < cols) o[m] = (uint8_t)(packed >> (8 * m));
             }
         }
     }
