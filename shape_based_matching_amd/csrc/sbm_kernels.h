@@ -232,7 +232,7 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
                                                   uint8_t* __restrict__ pyr_out)
 {
     __shared__ uint32_t s_src[CH][QS_R][QS_W / 4]; // u8 x4
-    __shared__ uint32_t s_h[CH][QS_R][QH_W / 2];   // u16 x2
+    __shared__ __attribute__((aligned(16))) uint32_t s_h[CH][QS_R][QH_W / 2]; // u16 x2
     __shared__ uint32_t s_sm[CH][QM_R][QH_W / 4];  // u8 x4
     __shared__ __attribute__((aligned(16))) uint32_t s_w[QQ_R][QH_W]; // vote word 1 << 4*label per pixel
     __shared__ uint32_t s_st[QQ_R][QH_W / 4];      // u8 x4: non-zero = magnitude above the weak threshold
@@ -398,24 +398,31 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
     if (tid >= nwork) {
         pyr_channels(0, 1);
     } else {
-        for (int it = tid; it < CH * QS_R * (QH_W / 4); it += nwork) {
-            const int k = it / (QS_R * (QH_W / 4)), rem = it - k * (QS_R * (QH_W / 4));
-            const int r = rem / (QH_W / 4), g = rem - r * (QH_W / 4);
-            const uint32_t d0 = s_src[k][r][g], d1 = s_src[k][r][g + 1], d2 = s_src[k][r][g + 2];
+        // an item = 8 outputs (two dwords of s_src columns): 4 source dwords, 16 v_dot4
+        static_assert((QH_W / 4) % 2 == 0, "pairs of 4-pixel groups");
+        for (int it = tid; it < CH * QS_R * (QH_W / 8); it += nwork) {
+            const int k = it / (QS_R * (QH_W / 8)), rem = it - k * (QS_R * (QH_W / 8));
+            const int r = rem / (QH_W / 8), g = 2 * (rem - r * (QH_W / 8));
+            const uint32_t d0 = s_src[k][r][g], d1 = s_src[k][r][g + 1], d2 = s_src[k][r][g + 2], d3 = s_src[k][r][g + 3];
             const uint32_t KLO = 0x48381C08u; // 8, 28, 56, 72
             const uint32_t KHI = 0x00081C38u; // 56, 28, 8, 0
-            uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), KLO, 0u, false);
-            h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), KHI, h0, false);
-            uint32_t h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), KLO, 0u, false);
-            h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), KHI, h1, false);
-            uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), KLO, 0u, false);
-            h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), KHI, h2, false);
-            uint32_t h3 = __builtin_amdgcn_udot4(d1, KLO, 0u, false);
-            h3 = __builtin_amdgcn_udot4(d2, KHI, h3, false);
-            s_h[k][r][2 * g] = h0 | (h1 << 16);
-            s_h[k][r][2 * g + 1] = h2 | (h3 << 16);
+            const uint32_t a1 = __builtin_amdgcn_alignbyte(d1, d0, 1), a2 = __builtin_amdgcn_alignbyte(d1, d0, 2), a3 = __builtin_amdgcn_alignbyte(d1, d0, 3);
+            const uint32_t b1 = __builtin_amdgcn_alignbyte(d2, d1, 1), b2 = __builtin_amdgcn_alignbyte(d2, d1, 2), b3 = __builtin_amdgcn_alignbyte(d2, d1, 3);
+            const uint32_t c1 = __builtin_amdgcn_alignbyte(d3, d2, 1), c2 = __builtin_amdgcn_alignbyte(d3, d2, 2), c3 = __builtin_amdgcn_alignbyte(d3, d2, 3);
+            const uint32_t h0 = __builtin_amdgcn_udot4(b1, KHI, __builtin_amdgcn_udot4(a1, KLO, 0u, false), false);
+            const uint32_t h1 = __builtin_amdgcn_udot4(b2, KHI, __builtin_amdgcn_udot4(a2, KLO, 0u, false), false);
+            const uint32_t h2 = __builtin_amdgcn_udot4(b3, KHI, __builtin_amdgcn_udot4(a3, KLO, 0u, false), false);
+            const uint32_t h3 = __builtin_amdgcn_udot4(d2, KHI, __builtin_amdgcn_udot4(d1, KLO, 0u, false), false);
+            const uint32_t h4 = __builtin_amdgcn_udot4(c1, KHI, __builtin_amdgcn_udot4(b1, KLO, 0u, false), false);
+            const uint32_t h5 = __builtin_amdgcn_udot4(c2, KHI, __builtin_amdgcn_udot4(b2, KLO, 0u, false), false);
+            const uint32_t h6 = __builtin_amdgcn_udot4(c3, KHI, __builtin_amdgcn_udot4(b3, KLO, 0u, false), false);
+            const uint32_t h7 = __builtin_amdgcn_udot4(d3, KHI, __builtin_amdgcn_udot4(d2, KLO, 0u, false), false);
+            *(uint4*)&s_h[k][r][2 * g] = make_uint4(h0 | (h1 << 16), h2 | (h3 << 16), h4 | (h5 << 16), h6 | (h7 << 16));
         }
     }
+#ifdef SBM_QSTAMP_B
+    QSTAMP_WAVES(24)
+#endif
     lds_barrier();
     QSTAMP(3)
 
@@ -450,8 +457,10 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
         }
     }
     QSTAMP(7)
+#ifndef SBM_QSTAMP_B
     QSTAMP_WAVES(24)
-#if defined(SBM_QSTAMP) && !defined(SBM_QSTAMP_LIGHT)
+#endif
+#if defined(SBM_QSTAMP) && !defined(SBM_QSTAMP_LIGHT) && !defined(SBM_QSTAMP_B)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // split the barrier: LDS drain, then arrival
     QSTAMP_WAVES(40)
 #endif

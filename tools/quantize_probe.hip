@@ -4,6 +4,11 @@
 #ifndef SBM_NO_QSTAMP
 #define SBM_QSTAMP
 #endif
+#ifdef SBM_QSTAMP_B
+#define STAMP_BASE 10 /* per-wave stamps sit at the end of phase B: relative to the start of B */
+#else
+#define STAMP_BASE 11
+#endif
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -137,7 +142,7 @@ int main(int argc, char** argv)
                 if (st[t * 64] - t0 > 30) continue;
                 const double lt = (st[t * 64 + 6] - st[t * 64]) / 100.0;
                 if ((pass == 0) != (lt < 6.3)) continue;
-                for (int w = 0; w < 16; ++w) wv[w].push_back((double)st[t * 64 + 24 + w] - (double)st[t * 64 + 11]);
+                for (int w = 0; w < 16; ++w) wv[w].push_back((double)st[t * 64 + 24 + w] - (double)st[t * 64 + STAMP_BASE]);
             }
             if (!wv[0].empty()) { printf("   C done, per wave (cyc after C start):"); for (int w = 0; w < 16; ++w) { std::sort(wv[w].begin(), wv[w].end()); printf(" %.0f", wv[w][wv[w].size() / 2]); } printf("\n"); }
             std::vector<std::vector<double>> wd(16);
