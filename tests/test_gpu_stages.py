@@ -49,6 +49,36 @@ def test_quantize_case1_train_image(oracle, ctx_factory, case1):
     assert np.array_equal(gang, ang) and np.array_equal(bits(gmag), bits(mag)) and np.array_equal(bits(gori), bits(ori))
 
 
+@pytest.mark.parametrize("shape,T", [
+    ((32, 22), (1, 1)),     # 4-pixel groups straddle the right edge, odd width at level 1
+    ((64, 70), (1, 1)),     # one full tile + a 6-column remainder, 35 columns at level 1
+    ((96, 66), (1, 1)),
+    ((64, 2), (1, 1)),      # narrower than the pyrDown kernel: the literal reflect loop
+    ((2, 64), (1, 1)),
+    ((16, 11), (1,)),       # odd width, single level
+    ((48, 3), (1,)),
+    ((144, 208), (1, 1, 1)),  # three levels: 72 x 104, 36 x 52
+    ((128, 192), (4, 8)),
+])
+@pytest.mark.parametrize("ch", [1, 3])
+def test_pyramid_awkward_geometries(oracle, ctx_factory, shape, T, ch):
+    """the match() gradient path (integer binning, flat-tile shortcut, pyrDown fused into the tile kernel,
+    image-border handling of every phase) on frame sizes that are not multiples of the tile or of 4"""
+    rs = np.random.RandomState(shape[0] * 1000 + shape[1] + ch)
+    noise = rs.randint(0, 256, size=shape if ch == 1 else shape + (3,)).astype(np.uint8)
+    scene = synth.scene_gray(3, *shape, n_shapes=12) if ch == 1 else synth.scene_bgr(4, *shape, n_shapes=12)
+    flat = np.full_like(noise, 77)  # every tile constant: the shortcut path, pyrDown included
+    half = noise.copy()
+    half[:, : shape[1] // 2] = 200  # constant tiles next to textured ones
+    ctx = ctx_factory(T=T, weak=10.0)
+    for img in (noise, scene, flat, half):
+        ctx.build_pyramid(img)
+        pyr = oracle.Pyramid.build(img, list(T), 10.0)
+        for l in range(len(T)):
+            assert np.array_equal(ctx.get_quantized(l), pyr.quantized(l)), (shape, ch, l)
+        pyr.free()
+
+
 @pytest.mark.parametrize("shape", [(64, 96), (37, 51), (480, 640), (2, 2)])
 @pytest.mark.parametrize("ch", [1, 3])
 def test_pyrdown(oracle, ctx_factory, shape, ch):
