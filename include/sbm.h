@@ -97,6 +97,18 @@ int sbm_match_device(sbm_ctx* ctx, const void* d_img, int32_t rows, int32_t cols
                      int32_t channels, const void* d_mask, float threshold, void* d_out,
                      int64_t cap, void* d_count, void* stream);
 
+/* A batch of frames of one geometry in one call (the streaming row; the reference
+ * calls Detector::match once per frame, line2Dup.cpp:1078).  Frame f starts at d_imgs + f * frame_stride
+ * bytes; every kernel of the path is launched once for the whole batch (the frame is a grid dimension), so
+ * the per-launch cost is shared by n_frames frames.  Results of frame f: records at d_out + f * cap,
+ * {n_matches, overflow} at d_counts + 2 * f (int32); a result mirror (sbm_set_result_mirror) must hold
+ * n_frames * cap records and n_frames * 2 int32, laid out the same way.  The mask, if any, is shared by
+ * the frames.  Needs the register-only linear-memory kernel: T in {4, 8}, level widths multiples of 16.
+ * Each frame's list is what sbm_match_device returns for that frame alone. */
+int sbm_match_batch_device(sbm_ctx* ctx, const void* d_imgs, int64_t frame_stride, int32_t n_frames, int32_t rows,
+                           int32_t cols, int32_t stride, int32_t channels, const void* d_mask, float threshold,
+                           void* d_out, int64_t cap, void* d_counts, void* stream);
+
 /* sbm_match_device records its kernel sequence once per distinct argument tuple
  * as a hipGraph (two branches: the fine levels' linear memories are built
  * while the coarse-level chain runs) and replays it with one hipGraphLaunch per

@@ -21,7 +21,7 @@ SBM_MAX_LEVELS = 8
 # every symbol include/sbm.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "sbm_last_error", "sbm_abi_version", "sbm_create", "sbm_destroy", "sbm_upload_templates",
-    "sbm_select_classes", "sbm_select_range", "sbm_match", "sbm_match_device", "sbm_canonicalize",
+    "sbm_select_classes", "sbm_select_range", "sbm_match", "sbm_match_device", "sbm_match_batch_device", "sbm_canonicalize",
     "sbm_build_pyramid", "sbm_set_quantized", "sbm_get_quantized", "sbm_get_linear_memories",
     "sbm_level_dims", "sbm_match_templates", "sbm_quantized_orientations", "sbm_pyrdown", "sbm_spread",
     "sbm_compute_response_maps", "sbm_linearize", "sbm_similarity", "sbm_similarity_local",
@@ -73,6 +73,7 @@ def lib() -> C.CDLL:
     L.sbm_select_range.argtypes = [vp, i32, i32]
     L.sbm_match.argtypes = [vp, vp, i32, i32, i32, i32, vp, f32, vp, i64, C.POINTER(i64)]
     L.sbm_match_device.argtypes = [vp, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp]
+    L.sbm_match_batch_device.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp]
     L.sbm_canonicalize.argtypes = [vp, i64]
     L.sbm_canonicalize.restype = i64
     L.sbm_build_pyramid.argtypes = [vp, vp, i32, i32, i32, i32, vp]
@@ -195,6 +196,16 @@ class Context:
                                       C.c_void_p(d_mask) if d_mask else None, C.c_float(threshold),
                                       C.c_void_p(d_out), cap, C.c_void_p(d_count),
                                       C.c_void_p(stream) if stream else None))
+
+    def match_batch_device(self, d_imgs: int, frame_stride: int, n_frames: int, rows: int, cols: int, stride: int,
+                           channels: int, threshold: float, d_out: int, cap: int, d_counts: int, stream: int = 0,
+                           d_mask: int = 0):
+        """n_frames frames (frame f at d_imgs + f*frame_stride) in one launch of every kernel; frame f's records
+        at d_out + f*cap records, its {n, overflow} at d_counts + 2*f int32."""
+        _check(lib().sbm_match_batch_device(self._h, C.c_void_p(d_imgs), frame_stride, n_frames, rows, cols, stride,
+                                            channels, C.c_void_p(d_mask) if d_mask else None, C.c_float(threshold),
+                                            C.c_void_p(d_out), cap, C.c_void_p(d_counts),
+                                            C.c_void_p(stream) if stream else None))
 
     def set_result_mirror(self, mirror_out: int, mirror_count: int):
         """Device-visible (e.g. pinned host) addresses that receive a copy of every result."""

@@ -107,6 +107,7 @@ struct sbm_ctx {
     // pyramid
     int rows[SBM_MAX_LEVELS]{}, cols[SBM_MAX_LEVELS]{};
     int channels = 0;
+    int batch = 1;        // frames the per-level buffers, candidate lists and counters are allocated for
     int levels_valid = 0; // number of levels whose linear memories are resident
     int64_t lm_stride[SBM_MAX_LEVELS]{};
     DevBuf d_img[SBM_MAX_LEVELS], d_mask[SBM_MAX_LEVELS], d_quant[SBM_MAX_LEVELS], d_lm[SBM_MAX_LEVELS];
@@ -235,10 +236,11 @@ int check_level_dims(int rows, int cols, int T)
 }
 
 // (re)allocate the per-level buffers for a level-0 geometry
-int ensure_geometry(sbm_ctx* c, int rows, int cols, int channels)
+int ensure_geometry(sbm_ctx* c, int rows, int cols, int channels, int frames = 1)
 {
     if (channels != 1 && channels != 3) return fail(SBM_ERR_INVALID, "channels must be 1 or 3, got %d", channels);
-    bool same = c->channels == channels && c->rows[0] == rows && c->cols[0] == cols && c->d_lm[c->L - 1].p;
+    if (frames < 1 || frames > 65535) return fail(SBM_ERR_INVALID, "batch of %d frames out of range", frames);
+    bool same = c->channels == channels && c->rows[0] == rows && c->cols[0] == cols && c->d_lm[c->L - 1].p && frames <= c->batch;
     int r = rows, cc = cols;
     for (int l = 0; l < c->L; ++l) {
         if (l > 0) {
@@ -249,6 +251,7 @@ int ensure_geometry(sbm_ctx* c, int rows, int cols, int channels)
         if (c->rows[l] != r || c->cols[l] != cc) same = false;
     }
     if (same) return 0;
+    const size_t B = (size_t)std::max(frames, c->batch);
     r = rows;
     cc = cols;
     for (int l = 0; l < c->L; ++l) {
@@ -259,11 +262,17 @@ int ensure_geometry(sbm_ctx* c, int rows, int cols, int channels)
         c->rows[l] = r;
         c->cols[l] = cc;
         c->lm_stride[l] = lm_stride_for(r, cc, c->cfg.T[l]);
-        if (int e = c->d_img[l].ensure((size_t)r * cc * channels)) return e;
+        if (int e = c->d_img[l].ensure(B * r * cc * channels)) return e;
         if (int e = c->d_mask[l].ensure((size_t)r * cc)) return e;
-        if (int e = c->d_quant[l].ensure((size_t)r * cc)) return e;
+        if (int e = c->d_quant[l].ensure(B * r * cc)) return e;
         c->d_lm[l].release(); // fresh, zeroed: the tail past T*T*W*H must read as 0
-        if (int e = c->d_lm[l].ensure((size_t)8 * c->lm_stride[l], true)) return e;
+        if (int e = c->d_lm[l].ensure(B * 8 * c->lm_stride[l], true)) return e;
+    }
+    if (B > (size_t)c->batch) { // per-frame candidate lists and counters
+        if (int e = c->d_cands.ensure(B * c->cand_cap * sizeof(Cand))) return e;
+        c->d_counters.release();
+        if (int e = c->d_counters.ensure(B * 40 * sizeof(int32_t) + 256, true)) return e;
+        c->batch = (int)B;
     }
     c->channels = channels;
     c->foff_dirty = true;
@@ -307,19 +316,21 @@ int upload_geo(sbm_ctx* c, hipStream_t s)
 }
 
 int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, int cols, int stride, int ch,
-                    const uint8_t* d_mask, float weak, uint8_t* d_out, float* d_mag, float* d_ori, uint8_t* d_pyr)
+                    const uint8_t* d_mask, float weak, uint8_t* d_out, float* d_mag, float* d_ori, uint8_t* d_pyr,
+                    int frames = 1, int64_t img_fs = 0)
 {
-    dim3 grid((cols + QT_C - 1) / QT_C, (rows + QT_R - 1) / QT_R);
+    dim3 grid((cols + QT_C - 1) / QT_C, (rows + QT_R - 1) / QT_R, frames);
     const float thr_sq = weak * weak;
     const bool wf = d_mag || d_ori;
+    const int64_t out_fs = (int64_t)rows * cols, pyr_fs = (int64_t)(rows / 2) * (cols / 2) * ch; // the context's own per-frame buffers
     if (ch == 1 && !wf)
-        SBM_LAUNCH(c, "k_quantize", (k_quantize<1, false>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
+        SBM_LAUNCH(c, "k_quantize", (k_quantize<1, false>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr, img_fs, out_fs, pyr_fs);
     else if (ch == 1)
-        SBM_LAUNCH(c, "k_quantize", (k_quantize<1, true>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
+        SBM_LAUNCH(c, "k_quantize", (k_quantize<1, true>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr, img_fs, out_fs, pyr_fs);
     else if (!wf)
-        SBM_LAUNCH(c, "k_quantize", (k_quantize<3, false>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
+        SBM_LAUNCH(c, "k_quantize", (k_quantize<3, false>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr, img_fs, out_fs, pyr_fs);
     else
-        SBM_LAUNCH(c, "k_quantize", (k_quantize<3, true>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr);
+        SBM_LAUNCH(c, "k_quantize", (k_quantize<3, true>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr, img_fs, out_fs, pyr_fs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -338,7 +349,7 @@ int launch_build_lm(sbm_ctx* c, hipStream_t s, const uint8_t* d_q, int rows, int
         LmArgs a;
         memset(&a, 0, sizeof a);
         a.n_levels = 1;
-        a.lv[0] = LmLevelArgs{d_q, d_lm, lm_stride, rows, cols, W, H, T, 0};
+        a.lv[0] = LmLevelArgs{d_q, d_lm, lm_stride, rows, cols, W, H, T, 0, 0, 0};
         const int64_t items = (int64_t)rows * (W >> 2);
         SBM_LAUNCH(c, "k_build_lm", k_build_lm_rows, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
@@ -427,7 +438,7 @@ int ensure_foff(sbm_ctx* c, hipStream_t s)
 // reset_count != null: the linear-memory launch also zeroes the per-frame counters and *reset_count
 // (c->counters_fresh tells enqueue_coarse to skip its own k_reset launch).
 int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride0, const uint8_t* d_mask0,
-                    int32_t* reset_count = nullptr)
+                    int32_t* reset_count = nullptr, int frames = 1, int64_t img0_fs = 0)
 {
     const int ch = c->channels;
     const uint8_t* img = d_img0;
@@ -452,8 +463,10 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
         }
         if (int e = launch_quantize(c, s, img, c->rows[l], c->cols[l], stride, ch, mask, c->cfg.weak_threshold,
                                     c->d_quant[l].as<uint8_t>(), nullptr, nullptr,
-                                    l + 1 < c->L ? c->d_img[l + 1].as<uint8_t>() : nullptr))
+                                    l + 1 < c->L ? c->d_img[l + 1].as<uint8_t>() : nullptr, frames,
+                                    l == 0 ? img0_fs : (int64_t)c->rows[l] * c->cols[l] * ch))
             return e;
+        if (!all_rows && frames > 1) return fail(SBM_ERR_INVALID, "batched match needs T in {4, 8} and 16-column-aligned levels");
         if (!all_rows)
             if (int e = launch_build_lm(c, s, c->d_quant[l].as<uint8_t>(), c->rows[l], c->cols[l], c->cfg.T[l],
                                         c->d_lm[l].as<uint8_t>(), c->lm_stride[l]))
@@ -466,7 +479,8 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
         int blocks = 0;
         for (int l = 0; l < c->L; ++l) {
             const int T = c->cfg.T[l], W = c->cols[l] / T, H = c->rows[l] / T;
-            a.lv[l] = LmLevelArgs{c->d_quant[l].as<uint8_t>(), c->d_lm[l].as<uint8_t>(), c->lm_stride[l], c->rows[l], c->cols[l], W, H, T, blocks};
+            a.lv[l] = LmLevelArgs{c->d_quant[l].as<uint8_t>(), c->d_lm[l].as<uint8_t>(), c->lm_stride[l], c->rows[l], c->cols[l], W, H, T, blocks,
+                                  (int64_t)c->rows[l] * c->cols[l], (int64_t)8 * c->lm_stride[l]};
             blocks += (int)(((int64_t)c->rows[l] * (W >> 2) + 255) / 256);
         }
         if (reset_count) {
@@ -474,7 +488,7 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
             a.out_count = reset_count;
             c->counters_fresh = true;
         }
-        SBM_LAUNCH(c, "k_build_lm", k_build_lm_rows, dim3(blocks), dim3(256), 0, s, a);
+        SBM_LAUNCH(c, "k_build_lm", k_build_lm_rows, dim3(blocks, frames), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
     }
     c->levels_valid = c->L;
@@ -492,10 +506,11 @@ int prepare_templates(sbm_ctx* c, hipStream_t s, float threshold, int64_t cap)
 }
 
 // coarse pass over the active templates (reset + k_similarity_coarse; single-level pyramids emit here)
-int enqueue_coarse(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap, int32_t* d_count)
+int enqueue_coarse(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap, int32_t* d_count, int frames = 1)
 {
     const int L = c->L, lc = L - 1;
     int32_t* counters = c->d_counters.as<int32_t>();
+    if (!c->counters_fresh && frames > 1) return fail(SBM_ERR_STATE, "batched template loop without a batched pyramid");
     if (!c->counters_fresh) hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s, counters, d_count);
     c->counters_fresh = false;
     const int n_active = (int)c->h_active.size();
@@ -519,16 +534,16 @@ int enqueue_coarse(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap,
         }
         for (int first = 0; first < n_active; first += 65535) {
             const int cnt = std::min(65535, n_active - first);
-            SBM_LAUNCH(c, "k_similarity_coarse", k_similarity_coarse, dim3(chunks, cnt), dim3(256), 0, s, c->d_lm[lc].as<uint8_t>(),
+            SBM_LAUNCH(c, "k_similarity_coarse", k_similarity_coarse, dim3(chunks, cnt, frames), dim3(256), 0, s, c->d_lm[lc].as<uint8_t>(),
                                c->lm_stride[lc], c->rows[lc], c->cols[lc], T, W, H, L, lc, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(),
                                c->d_foff.as<int32_t>(), c->d_active.as<int32_t>() + first, c->d_rawmin.as<int32_t>(),
                                c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
-                               c->d_cands.as<Cand>(), counters, (int)c->cand_cap);
+                               c->d_cands.as<Cand>(), counters, (int)c->cand_cap, (int64_t)8 * c->lm_stride[lc]);
         }
         HIP_TRY(hipGetLastError());
     }
     if (L == 1) {
-        SBM_LAUNCH(c, "k_emit_coarse", k_emit_coarse, dim3(256), dim3(256), 0, s, c->d_cands.as<Cand>(), counters, (int)c->cand_cap,
+        SBM_LAUNCH(c, "k_emit_coarse", k_emit_coarse, dim3(256, frames), dim3(256), 0, s, c->d_cands.as<Cand>(), counters, (int)c->cand_cap,
                            c->d_tls.as<DevTL>(), L, lc, c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(), d_out, d_count,
                            (int)cap, c->mirror_out, c->mirror_count);
         HIP_TRY(hipGetLastError());
@@ -537,17 +552,17 @@ int enqueue_coarse(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap,
 }
 
 // refinement passes, finest level last (emits the match records)
-int enqueue_local(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap, int32_t* d_count)
+int enqueue_local(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap, int32_t* d_count, int frames = 1)
 {
     const int L = c->L;
     int32_t* counters = c->d_counters.as<int32_t>();
     for (int l = L - 2; l >= 0; --l) {
         const int T = c->cfg.T[l], W = c->cols[l] / T, H = c->rows[l] / T;
-        SBM_LAUNCH(c, "k_similarity_local", k_similarity_local, dim3(512), dim3(64 * LOCAL_WAVES), 0, s, c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
+        SBM_LAUNCH(c, "k_similarity_local", k_similarity_local, dim3(512, frames), dim3(64 * LOCAL_WAVES), 0, s, c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
                            c->rows[l], c->cols[l], T, W, H, L, l, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(), c->d_foff.as<int32_t>(),
                            c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
                            c->d_cands.as<Cand>(), counters, (int)c->cand_cap, l == 0 ? 1 : 0, d_out, d_count, (int)cap,
-                           c->mirror_out, c->mirror_count, c->profiling ? 1 : 0);
+                           c->mirror_out, c->mirror_count, c->profiling ? 1 : 0, (int64_t)8 * c->lm_stride[l]);
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -885,6 +900,28 @@ int sbm_match_device(sbm_ctx* c, const void* d_img, int32_t rows, int32_t cols, 
     c->levels_valid = c->L;
     HIP_TRY(hipGraphLaunch(hit->exec, s));
     return 0;
+}
+
+int sbm_match_batch_device(sbm_ctx* c, const void* d_imgs, int64_t frame_stride, int32_t n_frames, int32_t rows, int32_t cols,
+                           int32_t stride, int32_t channels, const void* d_mask, float threshold, void* d_out, int64_t cap,
+                           void* d_counts, void* stream)
+{
+    if (!c || !d_imgs || !d_out || !d_counts) return fail(SBM_ERR_INVALID, "null argument");
+    if (n_frames < 1) return fail(SBM_ERR_INVALID, "n_frames must be >= 1");
+    if (stride < cols * channels) return fail(SBM_ERR_INVALID, "stride %d < cols*channels", stride);
+    if (n_frames > 1 && frame_stride < (int64_t)stride * rows) return fail(SBM_ERR_INVALID, "frame_stride smaller than one frame");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const bool dirty = !(c->channels == channels && c->rows[0] == rows && c->cols[0] == cols && c->levels_valid == c->L &&
+                         n_frames <= c->batch) ||
+                       !c->have_thr || memcmp(&threshold, &c->thr_cached, 4) != 0 || c->foff_dirty;
+    if (dirty) HIP_TRY(hipDeviceSynchronize());
+    if (int e = ensure_geometry(c, rows, cols, channels, n_frames)) return e;
+    if (c->profiling) c->clear_timings();
+    if (int e = prepare_templates(c, c->stream, threshold, cap)) return e;
+    if (int e = enqueue_pyramid(c, s, (const uint8_t*)d_imgs, stride, (const uint8_t*)d_mask, (int32_t*)d_counts, n_frames, frame_stride)) return e;
+    if (int e = enqueue_coarse(c, s, (sbm_match_rec*)d_out, cap, (int32_t*)d_counts, n_frames)) return e;
+    return enqueue_local(c, s, (sbm_match_rec*)d_out, cap, (int32_t*)d_counts, n_frames);
 }
 
 int sbm_match_templates_device(sbm_ctx* c, float threshold, void* d_out, int64_t cap, void* d_count, void* stream)

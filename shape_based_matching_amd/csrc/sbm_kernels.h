@@ -229,8 +229,13 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
                                                   int stride, const uint8_t* __restrict__ mask,
                                                   float thr_sq, uint8_t* __restrict__ out,
                                                   float* __restrict__ mag_out, float* __restrict__ ori_out,
-                                                  uint8_t* __restrict__ pyr_out)
+                                                  uint8_t* __restrict__ pyr_out, int64_t img_fs, int64_t out_fs,
+                                                  int64_t pyr_fs)
 {
+    // a batch of frames of one geometry: frame = blockIdx.z, *_fs = bytes from one frame to the next
+    img += (size_t)blockIdx.z * img_fs;
+    out += (size_t)blockIdx.z * out_fs;
+    if (pyr_out) pyr_out += (size_t)blockIdx.z * pyr_fs;
     __shared__ uint32_t s_src[CH][QS_R][QS_W / 4]; // u8 x4
     __shared__ __attribute__((aligned(16))) uint32_t s_h[CH][QS_R][QH_W / 2]; // u16 x2
     __shared__ uint32_t s_sm[CH][QM_R][QH_W / 4];  // u8 x4
@@ -862,6 +867,7 @@ struct LmLevelArgs {
     int64_t lm_stride;
     int32_t rows, cols, W, H, T;
     int32_t block_begin; // first block of this level
+    int64_t q_fs, lm_fs; // bytes from one frame of a batch to the next
 };
 struct LmArgs {
     LmLevelArgs lv[SBM_MAX_LEVELS];
@@ -872,9 +878,10 @@ struct LmArgs {
 
 __global__ __launch_bounds__(256) void k_build_lm_rows(const LmArgs a)
 {
+    const size_t frame = blockIdx.y; // batch of frames: one grid row each
     if (blockIdx.x == 0 && a.counters) {
-        if (threadIdx.x < 40) a.counters[threadIdx.x] = 0;
-        if (threadIdx.x < 2 && a.out_count) a.out_count[threadIdx.x] = 0;
+        if (threadIdx.x < 40) a.counters[frame * 40 + threadIdx.x] = 0;
+        if (threadIdx.x < 2 && a.out_count) a.out_count[frame * 2 + threadIdx.x] = 0;
     }
     int l = 0;
 #pragma unroll
@@ -882,8 +889,10 @@ __global__ __launch_bounds__(256) void k_build_lm_rows(const LmArgs a)
         if (i < a.n_levels && (int)blockIdx.x >= a.lv[i].block_begin) l = i;
     const LmLevelArgs& p = a.lv[l];
     const int64_t item = (int64_t)((int)blockIdx.x - p.block_begin) * 256 + threadIdx.x;
-    if (p.T == 4) build_lm_rows_item<4>(p.q, p.rows, p.cols, p.W, p.H, p.lm, p.lm_stride, item);
-    else build_lm_rows_item<8>(p.q, p.rows, p.cols, p.W, p.H, p.lm, p.lm_stride, item);
+    const uint8_t* q = p.q + frame * p.q_fs;
+    uint8_t* lm = p.lm + frame * p.lm_fs;
+    if (p.T == 4) build_lm_rows_item<4>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item);
+    else build_lm_rows_item<8>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item);
 }
 
 // unfused single-function kernels (stage entry points / parity tests)
@@ -1143,8 +1152,12 @@ __global__ __launch_bounds__(256) void k_similarity_coarse(
     const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
     const int32_t* __restrict__ active, const int32_t* __restrict__ raw_min, const int32_t* __restrict__ raw_keep,
     const int32_t* __restrict__ class_idx, const int32_t* __restrict__ template_id, Cand* __restrict__ cands,
-    int32_t* __restrict__ counters, int cap)
+    int32_t* __restrict__ counters, int cap, int64_t lm_fs)
 {
+    // batch of frames: frame = blockIdx.z; per-frame linear memories, candidate list and counters
+    lm += (size_t)blockIdx.z * lm_fs;
+    cands += (size_t)blockIdx.z * cap;
+    counters += (size_t)blockIdx.z * 40;
     __shared__ uint32_t s_red[4][8][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // XCD-aware (chunk, template) assignment.  Workgroups are dealt to the 8 XCDs round-robin by linear id,
@@ -1312,8 +1325,19 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
     const int32_t* __restrict__ raw_keep, const int32_t* __restrict__ class_idx,
     const int32_t* __restrict__ template_id, Cand* __restrict__ cands, int32_t* __restrict__ counters,
     int cand_cap, int is_last, sbm_match_rec* __restrict__ out, int32_t* __restrict__ out_count,
-    int out_cap, sbm_match_rec* __restrict__ mirror_out, int32_t* __restrict__ mirror_count, int collect_stats)
+    int out_cap, sbm_match_rec* __restrict__ mirror_out, int32_t* __restrict__ mirror_count, int collect_stats,
+    int64_t lm_fs)
 {
+    { // batch of frames: frame = blockIdx.y; per-frame linear memories, candidates, counters and result lists
+        const size_t frame = blockIdx.y;
+        lm += frame * lm_fs;
+        cands += frame * cand_cap;
+        counters += frame * 40;
+        out += frame * out_cap;
+        out_count += frame * 2;
+        if (mirror_out) mirror_out += frame * out_cap;
+        if (mirror_count) mirror_count += frame * 2;
+    }
     __shared__ uint32_t s_part[LOCAL_WAVES][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // the candidate count and this block's first candidate are fetched together (the record is read
@@ -1424,6 +1448,15 @@ __global__ __launch_bounds__(256) void k_emit_coarse(const Cand* __restrict__ ca
                                                      sbm_match_rec* __restrict__ mirror_out,
                                                      int32_t* __restrict__ mirror_count)
 {
+    { // batch of frames: frame = blockIdx.y
+        const size_t frame = blockIdx.y;
+        cands += frame * cand_cap;
+        counters += frame * 40;
+        out += frame * out_cap;
+        out_count += frame * 2;
+        if (mirror_out) mirror_out += frame * out_cap;
+        if (mirror_count) mirror_count += frame * 2;
+    }
     const int n_all = counters[0];
     const int n = n_all < cand_cap ? n_all : cand_cap;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {

@@ -123,3 +123,66 @@ def test_match_device_sharded_world1(oracle, ctx_factory, case1):
         n, overflow = buf[:8].view(np.int32)
         assert overflow == 0 and n == len(want)
         assert key(buf[hdr:].view(MATCH_DTYPE)[:n]) == key(want)
+
+
+@pytest.mark.parametrize("ch", [3, 1])
+def test_match_batch_device(oracle, ctx_factory, case1, ch):
+    """sbm_match_batch_device: several different frames in one launch of every kernel; each frame's list must be
+    the list of that frame alone (oracle), also after the batch size grows / shrinks and next to single-frame
+    calls on the same context, and the pinned-host mirror must hold the same lists."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    ts = case1["templates"].subset(range(280, 361, 2))
+    base = frame_of(case1)
+    frames = [base, np.ascontiguousarray(base[:, ::-1]), np.ascontiguousarray(base[::-1]), np.zeros_like(base),
+              np.roll(base, 48, axis=1)]
+    if ch == 1:
+        frames = [np.ascontiguousarray(f[:, :, 1]) for f in frames]
+    rows, cols = frames[0].shape[:2]
+    thr = 80.0
+    want = []
+    for fr in frames:
+        pyr = oracle.Pyramid.build(fr, [4, 8], 30.0)
+        want.append(pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr))
+        pyr.free()
+    assert len(want[0]) > 0 and len(want[3]) == 0
+    ctx = ctx_factory()
+    ctx.upload_templates(ts)
+    cap = 1024
+    rec = MATCH_DTYPE.itemsize
+    stream = torch.cuda.Stream(device=dev)
+    d_imgs = torch.from_numpy(np.stack(frames)).to(dev)
+    fs = rows * cols * ch
+    nmax = len(frames)
+    d_out = torch.zeros(nmax * cap * rec, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(nmax * 2, dtype=torch.int32, device=dev)
+    h_out = torch.zeros(nmax * cap * rec, dtype=torch.uint8).pin_memory()
+    h_cnt = torch.zeros(nmax * 2, dtype=torch.int32).pin_memory()
+
+    def check(n, first, mirror):
+        cnt = d_cnt.cpu().numpy().reshape(-1, 2)
+        out = d_out.cpu().numpy().reshape(nmax, cap * rec)
+        for f in range(n):
+            assert cnt[f, 1] == 0 and cnt[f, 0] == len(want[first + f]), (n, first, f, cnt[f], len(want[first + f]))
+            assert key(out[f].view(MATCH_DTYPE)[: cnt[f, 0]]) == key(want[first + f])
+            if mirror:
+                hc = h_cnt.numpy().reshape(-1, 2)
+                assert hc[f, 0] == cnt[f, 0] and hc[f, 1] == 0
+                assert key(h_out.numpy().reshape(nmax, cap * rec)[f].view(MATCH_DTYPE)[: hc[f, 0]]) == key(want[first + f])
+
+    for mirror in (False, True):
+        ctx.set_result_mirror(h_out.data_ptr() if mirror else 0, h_cnt.data_ptr() if mirror else 0)
+        for n, first in ((2, 0), (5, 0), (1, 2), (3, 2), (5, 0)):
+            d_cnt.fill_(-1)
+            h_cnt.fill_(-1)
+            ctx.match_batch_device(d_imgs.data_ptr() + first * fs, fs, n, rows, cols, cols * ch, ch, thr, d_out.data_ptr(), cap,
+                                   d_cnt.data_ptr(), stream=stream.cuda_stream)
+            stream.synchronize()
+            check(n, first, mirror)
+            # a single-frame call on the same context in between
+            ctx.match_device(d_imgs.data_ptr() + 1 * fs, rows, cols, cols * ch, ch, thr, d_out.data_ptr(), cap, d_cnt.data_ptr(),
+                             stream=stream.cuda_stream)
+            stream.synchronize()
+            c = d_cnt.cpu().numpy()
+            assert c[0] == len(want[1]) and key(d_out.cpu().numpy()[: cap * rec].view(MATCH_DTYPE)[: c[0]]) == key(want[1])
