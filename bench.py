@@ -30,7 +30,7 @@ ROWS = COLS = 1024
 N_TEMPLATES = 360
 THRESHOLD = 90.0
 T_LEVELS = (4, 8)
-PREFETCH = 1024  # capacity (records) of the per-frame match list exchanged between ranks / sent to the host
+PREFETCH = 256  # capacity (records) of the per-frame match list exchanged between ranks / sent to the host
 
 
 def load_workload(world: int, frame_kind: str = "case1"):
@@ -100,9 +100,12 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: run the N>1 code path (RCCL all-gathers + host copy) with whatever world size")
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=2,
                     help="frames in flight per GPU: independent engine contexts + HIP streams used round-robin "
                          "(1 = strictly one frame at a time; the single-stream figure is always reported too)")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="frames per step: a step is one sbm_match_batch_device call over this many frames (distinct "
+                         "horizontal shifts of the workload frame); 1 = one sbm_match_device call per step")
     ap.add_argument("--frame", choices=("case1", "tiled"), default="case1",
                     help="case1: the reference's test image centred on a black canvas (BASELINE configs[1]); "
                          "tiled: the same image repeated over the whole canvas (no constant regions)")
@@ -134,11 +137,17 @@ def main():
     first, count = sharding.partition(sharding.coarse_work(ts, ROWS, COLS, T_LEVELS), world)[rank]
 
     cap = PREFETCH
-    d_img = torch.from_numpy(frame).to(dev)
+    B = max(1, args.batch)
+    # frame b of a batch = the workload frame rolled b * 8 columns (same content, same work, different bytes)
+    batch_frames = np.stack([np.roll(frame, 8 * b, axis=1) for b in range(B)])
+    d_img = torch.from_numpy(batch_frames).to(dev)
+    FRAME_BYTES = ROWS * COLS * 3
 
     REC = MATCH_DTYPE.itemsize
-    HDR = 16  # {n_matches, overflow} + padding, in front of the records: one buffer, one collective, one copy
-    BUF = HDR + cap * REC
+    # per rank: B {n_matches, overflow} int32 pairs (padded to 16 bytes) in front of B blocks of cap records:
+    # one buffer, one collective, one copy
+    HDR = (8 * B + 15) // 16 * 16
+    BUF = HDR + B * cap * REC
 
     class Slot:
         """one frame in flight: its own engine context (device buffers), stream and result buffers"""
@@ -167,21 +176,30 @@ def main():
                 self.ctx.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
 
         def run(self):
-            if collective:
+            if collective and B > 1:
+                self.ctx.match_batch_device_sharded(d_img.data_ptr(), FRAME_BYTES, B, ROWS, COLS, COLS * 3, 3, THRESHOLD,
+                                                    self.d_buf.data_ptr(), cap, self.g_buf.data_ptr(),
+                                                    gathered_mirror=self.h_buf.data_ptr(), stream=self.stream.cuda_stream)
+            elif collective:
                 # match of this rank's template shard + the exchange step (ncclAllGather over xGMI, issued by the
                 # library on the same stream) + copy of the gathered lists into pinned host memory
                 self.ctx.match_device_sharded(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, self.d_buf.data_ptr(), cap,
                                               self.g_buf.data_ptr(), gathered_mirror=self.h_buf.data_ptr(),
                                               stream=self.stream.cuda_stream)
+            elif B > 1:
+                self.ctx.match_batch_device(d_img.data_ptr(), FRAME_BYTES, B, ROWS, COLS, COLS * 3, 3, THRESHOLD,
+                                            self.d_buf.data_ptr() + HDR, cap, self.d_buf.data_ptr(), stream=self.stream.cuda_stream)
             else:
                 self.ctx.match_device(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, self.d_buf.data_ptr() + HDR, cap,
                                       self.d_buf.data_ptr(), stream=self.stream.cuda_stream)
 
         def host_counts(self):
-            return self.h_buf.numpy().reshape(world, BUF)[:, :8].copy().view(np.int32).reshape(world, 2)
+            """[world][B][2] = {n_matches, overflow} per rank and frame of the step"""
+            return self.h_buf.numpy().reshape(world, BUF)[:, : 8 * B].copy().view(np.int32).reshape(world, B, 2)
 
         def host_records(self):
-            return self.h_buf.numpy().reshape(world, BUF)[:, HDR:].copy().view(MATCH_DTYPE).reshape(world, cap)
+            """[world][B][cap] match records"""
+            return self.h_buf.numpy().reshape(world, BUF)[:, HDR:].copy().view(MATCH_DTYPE).reshape(world, B, cap)
 
     slots = [Slot(None) for i in range(max(1, args.inflight))]
     ctx = slots[0].ctx
@@ -234,13 +252,29 @@ def main():
             c = sl.host_counts()
             if ref_counts is None:
                 ref_counts = c
-            if not np.array_equal(c, ref_counts) or c[:, 0].min() <= 0:
+            if not np.array_equal(c, ref_counts) or c[:, :, 0].min() <= 0:
                 raise SystemExit(f"unstable match counts: {c.tolist()} vs {ref_counts.tolist()}")
     counts = slots[0].host_counts()
-    if (counts[:, 1] != 0).any() or (counts[:, 0] > cap).any():
+    if (counts[:, :, 1] != 0).any() or (counts[:, :, 0] > cap).any():
         raise SystemExit(f"match list overflow: {counts.tolist()}")
     recs = slots[0].host_records()
-    matches = np.concatenate([recs[r, : counts[r, 0]] for r in range(world)])
+    if B > 1 and not collective:
+        # every frame of the batch against the single-frame entry point on the same frame
+        one_out = torch.zeros(cap * REC, dtype=torch.uint8, device=dev)
+        one_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+        ctx.set_result_mirror(0, 0)
+        for b in range(B):
+            ctx.match_device(d_img.data_ptr() + b * FRAME_BYTES, ROWS, COLS, COLS * 3, 3, THRESHOLD, one_out.data_ptr(), cap,
+                             one_cnt.data_ptr(), stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            n1 = int(one_cnt.cpu().numpy()[0])
+            single = capi.canonicalize(one_out.cpu().numpy().view(MATCH_DTYPE)[:n1].copy())
+            batched = capi.canonicalize(recs[0, b, : counts[0, b, 0]].copy())
+            if n1 != counts[0, b, 0] or single.tobytes() != batched.tobytes():
+                raise SystemExit(f"frame {b} of the batch differs from its single-frame match list")
+        ctx.set_result_mirror(slots[0].h_buf.data_ptr() + HDR, slots[0].h_buf.data_ptr())
+    # frame 0 of the step: every rank's list, gathered
+    matches = np.concatenate([recs[r, 0, : counts[r, 0, 0]] for r in range(world)])
     n_matches = len(capi.canonicalize(matches))
 
     # per-kernel durations: a second pass of the same steps with HIP events around every launch
@@ -249,8 +283,12 @@ def main():
     per_kernel = {}
     prof_steps = min(args.steps, 50)
     for _ in range(prof_steps):
-        ctx.match_device(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, slots[0].d_buf.data_ptr() + HDR, cap,
-                         slots[0].d_buf.data_ptr(), stream=stream.cuda_stream)
+        if B > 1:
+            ctx.match_batch_device(d_img.data_ptr(), FRAME_BYTES, B, ROWS, COLS, COLS * 3, 3, THRESHOLD,
+                                   slots[0].d_buf.data_ptr() + HDR, cap, slots[0].d_buf.data_ptr(), stream=stream.cuda_stream)
+        else:
+            ctx.match_device(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, slots[0].d_buf.data_ptr() + HDR, cap,
+                             slots[0].d_buf.data_ptr(), stream=stream.cuda_stream)
         torch.cuda.synchronize()
         for name, ms in ctx.timings():
             per_kernel.setdefault(name, []).append(ms)
@@ -262,11 +300,12 @@ def main():
         # algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md), by kernel
         npx = [(ROWS >> l) * (COLS >> l) for l in range(len(T_LEVELS))]
         alg = {
-            # frame read + one-hot map written (+ the next level's image, written by the fused pyrDown)
-            "k_quantize": [npx[0] * (3 + 1) + npx[1] * 3, npx[1] * (3 + 1)],
-            "k_build_lm": [sum(n * 9 for n in npx)],
-            "k_similarity_coarse": [coarse_bytes],
-            "k_similarity_local": [refine_bytes],
+            # frame read + one-hot map written (+ the next level's image, written by the fused pyrDown);
+            # a launch covers the B frames of the step (refinement bytes: frame 0's figure x B)
+            "k_quantize": [B * (npx[0] * (3 + 1) + npx[1] * 3), B * npx[1] * (3 + 1)],
+            "k_build_lm": [B * sum(n * 9 for n in npx)],
+            "k_similarity_coarse": [B * coarse_bytes],
+            "k_similarity_local": [B * refine_bytes],
         }
         kern = {}
         for name, v in per_kernel.items():
@@ -290,7 +329,7 @@ def main():
                 traffic = None
         step_bytes = float(sum(sum(v) for v in alg.values()))
         total_templates = ts.n_templates
-        value = total_templates * (ROWS * COLS / 1e6) * args.steps / elapsed
+        value = total_templates * (ROWS * COLS / 1e6) * B * args.steps / elapsed
         out = {
             "metric": "templates*Mpixels/sec (whole Detector::match, frame resident in HBM)",
             "value": value,
@@ -314,8 +353,10 @@ def main():
                 "templates_per_gpu": count,
                 "frame": [ROWS, COLS, 3],
                 "parallelism": f"template-shard x{world}" + (" + RCCL all-gather of match lists" if collective else ""),
-                "frames_in_flight": len(slots),
-                "ms_per_step_one_frame_at_a_time": single_ms,
+                "frames_per_step": B,
+                "us_per_frame": elapsed / args.steps / B * 1e6,
+                "frames_in_flight": len(slots) * B,
+                ("ms_per_step_one_frame_at_a_time" if B == 1 else "ms_per_step_one_batch_at_a_time"): single_ms,
                 "matches_distinct": n_matches,
                 "coarse_candidates_rank0": n_cand,
             },

@@ -151,6 +151,13 @@ int sbm_comm_destroy(sbm_ctx* ctx);
 int sbm_match_device_sharded(sbm_ctx* ctx, const void* d_img, int32_t rows, int32_t cols, int32_t stride,
                              int32_t channels, const void* d_mask, float threshold, void* d_local,
                              int64_t cap, void* d_gathered, void* gathered_mirror, void* stream);
+/* The same exchange for a batch of frames (sbm_match_batch_device + one ncclAllGather of the whole shard):
+ *   d_local : header = n_frames * 8 bytes rounded up to 16 ({n_matches, overflow} int32 pairs), then
+ *             n_frames blocks of cap records; d_gathered: world such shards in rank order. */
+int sbm_match_batch_device_sharded(sbm_ctx* ctx, const void* d_imgs, int64_t frame_stride, int32_t n_frames,
+                                   int32_t rows, int32_t cols, int32_t stride, int32_t channels,
+                                   const void* d_mask, float threshold, void* d_local, int64_t cap,
+                                   void* d_gathered, void* gathered_mirror, void* stream);
 
 /* Detector::match epilogue (line2Dup.cpp:1142-1145) in canonical form: sort by
  * (similarity desc, template_id asc, class_idx asc, y asc, x asc), drop exact

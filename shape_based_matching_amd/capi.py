@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "sbm_set_profiling", "sbm_get_timings", "sbm_coarse_bytes", "sbm_get_stats",
     "sbm_set_result_mirror", "sbm_set_graph_mode",
     "sbm_match_templates_device", "sbm_orientation_bins",
-    "sbm_comm_unique_id", "sbm_comm_init", "sbm_comm_destroy", "sbm_match_device_sharded",
+    "sbm_comm_unique_id", "sbm_comm_init", "sbm_comm_destroy", "sbm_match_device_sharded", "sbm_match_batch_device_sharded",
 ]
 
 
@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
     L.sbm_comm_init.argtypes = [vp, i32, i32, vp]
     L.sbm_comm_destroy.argtypes = [vp]
     L.sbm_match_device_sharded.argtypes = [vp, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp, vp]
+    L.sbm_match_batch_device_sharded.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp, vp]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
         if name not in ("sbm_last_error", "sbm_destroy", "sbm_canonicalize"):
@@ -231,6 +232,15 @@ class Context:
                                               C.c_void_p(d_local), cap, C.c_void_p(d_gathered),
                                               C.c_void_p(gathered_mirror) if gathered_mirror else None,
                                               C.c_void_p(stream) if stream else None))
+
+    def match_batch_device_sharded(self, d_imgs: int, frame_stride: int, n_frames: int, rows: int, cols: int, stride: int,
+                                   channels: int, threshold: float, d_local: int, cap: int, d_gathered: int,
+                                   gathered_mirror: int = 0, stream: int = 0, d_mask: int = 0):
+        _check(lib().sbm_match_batch_device_sharded(self._h, C.c_void_p(d_imgs), frame_stride, n_frames, rows, cols, stride,
+                                                    channels, C.c_void_p(d_mask) if d_mask else None, C.c_float(threshold),
+                                                    C.c_void_p(d_local), cap, C.c_void_p(d_gathered),
+                                                    C.c_void_p(gathered_mirror) if gathered_mirror else None,
+                                                    C.c_void_p(stream) if stream else None))
 
     def set_graph_mode(self, on: bool):
         _check(lib().sbm_set_graph_mode(self._h, 1 if on else 0))

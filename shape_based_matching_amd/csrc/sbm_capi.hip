@@ -323,14 +323,22 @@ int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, i
     const float thr_sq = weak * weak;
     const bool wf = d_mag || d_ori;
     const int64_t out_fs = (int64_t)rows * cols, pyr_fs = (int64_t)(rows / 2) * (cols / 2) * ch; // the context's own per-frame buffers
-    if (ch == 1 && !wf)
-        SBM_LAUNCH(c, "k_quantize", (k_quantize<1, false>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr, img_fs, out_fs, pyr_fs);
-    else if (ch == 1)
-        SBM_LAUNCH(c, "k_quantize", (k_quantize<1, true>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr, img_fs, out_fs, pyr_fs);
-    else if (!wf)
-        SBM_LAUNCH(c, "k_quantize", (k_quantize<3, false>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr, img_fs, out_fs, pyr_fs);
-    else
-        SBM_LAUNCH(c, "k_quantize", (k_quantize<3, true>), grid, dim3(QN), 0, s, d_img, rows, cols, stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr, img_fs, out_fs, pyr_fs);
+    // many tiles per CU (a batch of frames): 512-thread blocks, four of them per CU; else 1024-thread blocks (tile latency)
+    const bool many = (int64_t)grid.x * grid.y * grid.z >= 2048;
+#define SBM_QUANTIZE(CH_, WF_)                                                                                              \
+    do {                                                                                                                    \
+        if (many)                                                                                                           \
+            SBM_LAUNCH(c, "k_quantize", (k_quantize<CH_, WF_, QN_THROUGHPUT>), grid, dim3(QN_THROUGHPUT), 0, s, d_img, rows, cols, \
+                       stride, d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr, img_fs, out_fs, pyr_fs);                         \
+        else                                                                                                                \
+            SBM_LAUNCH(c, "k_quantize", (k_quantize<CH_, WF_, QN_LATENCY>), grid, dim3(QN_LATENCY), 0, s, d_img, rows, cols, stride, \
+                       d_mask, thr_sq, d_out, d_mag, d_ori, d_pyr, img_fs, out_fs, pyr_fs);                                 \
+    } while (0)
+    if (ch == 1 && !wf) SBM_QUANTIZE(1, false);
+    else if (ch == 1) SBM_QUANTIZE(1, true);
+    else if (!wf) SBM_QUANTIZE(3, false);
+    else SBM_QUANTIZE(3, true);
+#undef SBM_QUANTIZE
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -558,7 +566,8 @@ int enqueue_local(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap, 
     int32_t* counters = c->d_counters.as<int32_t>();
     for (int l = L - 2; l >= 0; --l) {
         const int T = c->cfg.T[l], W = c->cols[l] / T, H = c->rows[l] / T;
-        SBM_LAUNCH(c, "k_similarity_local", k_similarity_local, dim3(512, frames), dim3(64 * LOCAL_WAVES), 0, s, c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
+        static const int local_grid = getenv("SBM_LOCAL_GRID") ? std::max(1, atoi(getenv("SBM_LOCAL_GRID"))) : 512;
+        SBM_LAUNCH(c, "k_similarity_local", k_similarity_local, dim3(frames, local_grid), dim3(64 * LOCAL_WAVES), 0, s, c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
                            c->rows[l], c->cols[l], T, W, H, L, l, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(), c->d_foff.as<int32_t>(),
                            c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
                            c->d_cands.as<Cand>(), counters, (int)c->cand_cap, l == 0 ? 1 : 0, d_out, d_count, (int)cap,
@@ -1384,6 +1393,31 @@ extern "C" int sbm_match_device_sharded(sbm_ctx* c, const void* d_img, int32_t r
                                  d_local, s))
         return e;
     // the one exchange step of the path: every rank's list to every rank, over xGMI, on the same stream
+    int rc = g_rccl.AllGather(d_local, d_gathered, bytes, /* ncclUint8 */ 1, c->comm, s);
+    if (rc) return fail(SBM_ERR_HIP, "ncclAllGather: %s", rccl_err(rc));
+    if (gathered_mirror) {
+        const size_t total = bytes * (size_t)c->comm_world;
+        hipLaunchKernelGGL(k_copy_bytes, dim3((unsigned)std::min<size_t>((total / 16 + 255) / 256 + 1, 1024)), dim3(256), 0, s,
+                           (const uint8_t*)d_gathered, (uint8_t*)gathered_mirror, total);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int sbm_match_batch_device_sharded(sbm_ctx* c, const void* d_imgs, int64_t frame_stride, int32_t n_frames, int32_t rows,
+                                              int32_t cols, int32_t stride, int32_t channels, const void* d_mask, float threshold,
+                                              void* d_local, int64_t cap, void* d_gathered, void* gathered_mirror, void* stream)
+{
+    if (!c || !d_local || !d_gathered) return fail(SBM_ERR_INVALID, "null argument");
+    if (!c->comm) return fail(SBM_ERR_STATE, "sbm_comm_init has not been called on this context");
+    if (n_frames < 1) return fail(SBM_ERR_INVALID, "n_frames must be >= 1");
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // this rank's shard: n_frames {n_matches, overflow} pairs (padded to 16 bytes), then n_frames blocks of cap records
+    const size_t header = ((size_t)n_frames * 8 + 15) / 16 * 16;
+    const size_t bytes = header + (size_t)n_frames * (size_t)cap * sizeof(sbm_match_rec);
+    if (int e = sbm_match_batch_device(c, d_imgs, frame_stride, n_frames, rows, cols, stride, channels, d_mask, threshold,
+                                       (char*)d_local + header, cap, d_local, s))
+        return e;
     int rc = g_rccl.AllGather(d_local, d_gathered, bytes, /* ncclUint8 */ 1, c->comm, s);
     if (rc) return fail(SBM_ERR_HIP, "ncclAllGather: %s", rccl_err(rc));
     if (gathered_mirror) {

@@ -177,7 +177,11 @@ __device__ unsigned long long* g_qstamp = nullptr;
 #define QSTAMP(i)
 #define QSTAMP_WAVES(base)
 #endif
-constexpr int QN = 1024; // threads per tile: short per-wave instruction streams, 16 waves hide each other's latency
+// Threads per tile.  1024 (16 waves: short per-wave instruction streams, the waves hide each other's latency)
+// when a launch gives a CU one or two tiles -- tile latency is then the launch's duration; 512 when it gives
+// every CU many (a batch of frames): four tiles per CU instead of two overlap each other's barrier and LDS
+// stalls (measured: 4096 textured tiles 52.8 -> 46.0 us, 256 tiles 6.0 -> 7.0 us).
+constexpr int QN_LATENCY = 1024, QN_THROUGHPUT = 512;
 constexpr int QS_W = 80; // source tile width  (cols C0-8 .. C0+71)
 constexpr int QH_W = 72; // h / smoothed / q tile width (cols C0-4 .. C0+67)
 
@@ -224,7 +228,7 @@ __device__ __forceinline__ uint32_t vote_word(uint32_t v)
     return v ? w : 1u;
 }
 
-template <int CH, bool WITH_FLOAT>
+template <int CH, bool WITH_FLOAT, int QN>
 __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img, int rows, int cols,
                                                   int stride, const uint8_t* __restrict__ mask,
                                                   float thr_sq, uint8_t* __restrict__ out,
@@ -1258,15 +1262,15 @@ __global__ __launch_bounds__(256) void k_similarity_map(const uint8_t* __restric
 // read below sees every block's increments once all of them have arrived.
 __device__ __forceinline__ void publish_counts(int32_t* __restrict__ counters, int n_all, int n_work_blocks, bool worked,
                                                int cand_cap, int32_t* __restrict__ out_count,
-                                               int32_t* __restrict__ mirror_count)
+                                               int32_t* __restrict__ mirror_count, int slot)
 {
-    if (!worked && !(n_work_blocks == 0 && blockIdx.x == 0)) return; // block-uniform
+    if (!worked && !(n_work_blocks == 0 && slot == 0)) return; // block-uniform
     __syncthreads();
     if (threadIdx.x == 0) {
         bool last = n_work_blocks == 0;
         if (!last) {
             // two-level arrival (32 sub-counters): arrivals on one address serialise at ~25 ns each
-            const int sub = (int)blockIdx.x & 31;
+            const int sub = slot & 31;
             const int expect = (n_work_blocks - sub + 31) / 32; // working blocks with this residue
             const int groups = n_work_blocks < 32 ? n_work_blocks : 32;
             // no fence: the last block only reads out_count (device-scope atomics); the records themselves
@@ -1328,8 +1332,11 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
     int out_cap, sbm_match_rec* __restrict__ mirror_out, int32_t* __restrict__ mirror_count, int collect_stats,
     int64_t lm_fs)
 {
-    { // batch of frames: frame = blockIdx.y; per-frame linear memories, candidates, counters and result lists
-        const size_t frame = blockIdx.y;
+    // grid = (frames, candidate slots): the frame is the FAST grid dimension, so the blocks dispatched first are
+    // the low slots of every frame -- the ones that have a candidate -- and the idle slots come last
+    const int slot = blockIdx.y, n_slots = gridDim.y;
+    {
+        const size_t frame = blockIdx.x;
         lm += frame * lm_fs;
         cands += frame * cand_cap;
         counters += frame * 40;
@@ -1342,12 +1349,12 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // the candidate count and this block's first candidate are fetched together (the record is read
     // speculatively: the buffer always exists, the count decides whether it is used)
-    Cand c = cands[blockIdx.x < (unsigned)cand_cap ? blockIdx.x : 0];
+    Cand c = cands[slot < cand_cap ? slot : 0];
     const int n_all = counters[0];
     const int n = n_all < cand_cap ? n_all : cand_cap;
     const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
-    for (int ci = blockIdx.x; ci < n; ci += gridDim.x) {
-        if (ci != (int)blockIdx.x) c = cands[ci];
+    for (int ci = slot; ci < n; ci += n_slots) {
+        if (ci != slot) c = cands[ci];
         if (c.raw < 0) continue; // dropped at a coarser level (uniform per block)
         DevTL tl;
         tl.width = c.next_width;
@@ -1415,8 +1422,8 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
         }
     }
     if (is_last) {
-        const int n_work = n < (int)gridDim.x ? n : (int)gridDim.x;
-        publish_counts(counters, n_all, n_work, (int)blockIdx.x < n, cand_cap, out_count, mirror_count);
+        const int n_work = n < n_slots ? n : n_slots;
+        publish_counts(counters, n_all, n_work, slot < n, cand_cap, out_count, mirror_count, slot);
     }
 }
 
@@ -1479,7 +1486,7 @@ __global__ __launch_bounds__(256) void k_emit_coarse(const Cand* __restrict__ ca
         const int per = (int)gridDim.x * 256;
         const int n_work = (n + 255) / 256 < (int)gridDim.x ? (n + 255) / 256 : (int)gridDim.x;
         (void)per;
-        publish_counts(counters, n_all, n_work, (int)blockIdx.x < n_work, cand_cap, out_count, mirror_count);
+        publish_counts(counters, n_all, n_work, (int)blockIdx.x < n_work, cand_cap, out_count, mirror_count, (int)blockIdx.x);
     }
 }
 

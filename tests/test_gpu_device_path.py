@@ -124,6 +124,33 @@ def test_match_device_sharded_world1(oracle, ctx_factory, case1):
         assert overflow == 0 and n == len(want)
         assert key(buf[hdr:].view(MATCH_DTYPE)[:n]) == key(want)
 
+    # the batched exchange: 3 frames per call, one all-gather of the whole shard (header: 3 pairs, padded to 32 bytes)
+    frames = [frame, np.ascontiguousarray(frame[:, ::-1]), np.roll(frame, 40, axis=1)]
+    wants = []
+    for fr in frames:
+        p = oracle.Pyramid.build(fr, [4, 8], 30.0)
+        wants.append(p.match(shard.levels, shard.features, shard.class_idx, shard.template_id, 85.0))
+        p.free()
+    B = len(frames)
+    hdrb = (8 * B + 15) // 16 * 16
+    nbytes = hdrb + B * cap * rec
+    d_imgs = torch.from_numpy(np.stack(frames)).to(dev)
+    d_local = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    d_gath = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    h_gath = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+    fs = frame.shape[0] * frame.shape[1] * 3
+    for _ in range(3):
+        ctx.match_batch_device_sharded(d_imgs.data_ptr(), fs, B, frame.shape[0], frame.shape[1], frame.shape[1] * 3, 3, 85.0,
+                                       d_local.data_ptr(), cap, d_gath.data_ptr(), gathered_mirror=h_gath.data_ptr(),
+                                       stream=stream.cuda_stream)
+        stream.synchronize()
+    for buf in (d_gath.cpu().numpy(), h_gath.numpy()):
+        cnt = buf[: 8 * B].view(np.int32).reshape(B, 2)
+        for f in range(B):
+            assert cnt[f, 1] == 0 and cnt[f, 0] == len(wants[f]), f
+            got = buf[hdrb + f * cap * rec: hdrb + (f + 1) * cap * rec].view(MATCH_DTYPE)[: cnt[f, 0]]
+            assert key(got) == key(wants[f]), f
+
 
 @pytest.mark.parametrize("ch", [3, 1])
 def test_match_batch_device(oracle, ctx_factory, case1, ch):

@@ -10,6 +10,9 @@
 #include "../shape_based_matching_amd/csrc/sbm_kernels.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 using namespace sbm;
+#ifndef PROBE_QN
+#define PROBE_QN QN_LATENCY
+#endif
 __global__ void k_whoami(unsigned* out) { out[0] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); out[1] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); }
 int main()
 {
@@ -28,7 +31,7 @@ int main()
         mask[bit >> 5] = 1u << (bit & 31);
         hipStream_t s;
         if (hipExtStreamCreateWithCUMask(&s, 8, mask) != hipSuccess) { printf("mask bit %d refused\n", bit); continue; }
-        auto launch = [&] { hipLaunchKernelGGL((k_quantize<3, false>), grid, dim3(QN), 0, s, d_img, rows, cols, cols * 3, (const uint8_t*)nullptr, 900.f, d_out, (float*)nullptr, (float*)nullptr, d_pyr); };
+        auto launch = [&] { hipLaunchKernelGGL((k_quantize<3, false, PROBE_QN>), grid, dim3(PROBE_QN), 0, s, d_img, rows, cols, cols * 3, (const uint8_t*)nullptr, 900.f, d_out, (float*)nullptr, (float*)nullptr, d_pyr, (int64_t)0, (int64_t)0, (int64_t)0); };
         hipLaunchKernelGGL(k_whoami, dim3(1), dim3(64), 0, s, d_id);
         for (int i = 0; i < 5; ++i) launch();
         CK(hipEventRecord(a, s));

@@ -18,6 +18,9 @@
 #include "../shape_based_matching_amd/csrc/sbm_kernels.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 using namespace sbm;
+#ifndef PROBE_QN
+#define PROBE_QN QN_LATENCY
+#endif
 int main(int argc, char** argv)
 {
     const int rows = argc > 1 ? atoi(argv[1]) : 1024, cols = argc > 2 ? atoi(argv[2]) : 1024;
@@ -32,7 +35,7 @@ int main(int argc, char** argv)
     unsigned long long* d_st; CK(hipMalloc(&d_st, (size_t)nt * 64 * 8)); CK(hipMemset(d_st, 0, (size_t)nt * 64 * 8));
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    auto launch = [&] { hipLaunchKernelGGL((k_quantize<3, false>), grid, dim3(QN), 0, s, d_img, rows, cols, cols * 3, (const uint8_t*)nullptr, 900.f, d_out, (float*)nullptr, (float*)nullptr, d_pyr); };
+    auto launch = [&] { hipLaunchKernelGGL((k_quantize<3, false, PROBE_QN>), grid, dim3(PROBE_QN), 0, s, d_img, rows, cols, cols * 3, (const uint8_t*)nullptr, 900.f, d_out, (float*)nullptr, (float*)nullptr, d_pyr, (int64_t)0, (int64_t)0, (int64_t)0); };
     for (int i = 0; i < 300; ++i) launch();
     CK(hipEventRecord(a, s));
     for (int i = 0; i < 300; ++i) launch();
