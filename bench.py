@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the LINE-2D match() hot path on MI355X.
 
-A step = one Detector::match (line2Dup.cpp:1078-1150) of one frame that is
-already resident in HBM: gradient quantisation -> pyramid -> spread/response/
+A step = one pass of the hot path over one batch of frames that are already
+resident in HBM: for every frame one whole Detector::match
+(line2Dup.cpp:1078-1150) — gradient quantisation -> pyramid -> spread/response/
 linearize -> similarity over this rank's template shard -> 16x16 refinement ->
-match records, all-gathered over RCCL when N > 1 and copied to pinned host
-memory.  Metric: templates * Mpixels / s (BASELINE.json), whole job.
+match records — with the per-frame match lists all-gathered over RCCL when
+N > 1 and stored in pinned host memory.  Metric: templates * Mpixels / s
+(BASELINE.json), whole job: templates x Mpixels x frames per step x steps / time.
 
 Workload (BASELINE.json configs[1], "case1 on 1x MI355X"): the reference's
 case1 test image centred on a 1024 x 1024 BGR canvas, 360 case1 rotation
 templates (131 / 71 features) per GPU, pyramid {4, 8}, threshold 90.  With N
 GPUs the template set is N x 360 (weak scaling), sharded by contiguous ranges.
+--batch frames per step (default 8: sbm_match_batch_device launches every kernel
+once for the whole batch; frame b is the workload frame shifted 8*b columns) and
+--inflight independent slots (contexts + streams, default 2) used round-robin;
+--batch 1 --inflight 1 is strictly one frame at a time (sbm_match_device).
 
 Prints ONE JSON line on rank 0.
 """
@@ -277,22 +283,22 @@ def main():
     matches = np.concatenate([recs[r, 0, : counts[r, 0, 0]] for r in range(world)])
     n_matches = len(capi.canonicalize(matches))
 
-    # per-kernel durations: a second pass of the same steps with HIP events around every launch
-    # (on the launch stream), kept out of the timed region above
-    ctx.set_profiling(True)
+    # per-kernel durations: a second pass of the same steps, in the same configuration as the timed region (every
+    # slot, round-robin, nothing synchronised in between), with the dispatch packets' own start/stop timestamps
+    # (hipExtLaunchKernelGGL events on the launch stream); kept out of the timed region above
+    for sl in slots:
+        sl.ctx.set_profiling(True, accumulate=True)
     per_kernel = {}
     prof_steps = min(args.steps, 50)
-    for _ in range(prof_steps):
-        if B > 1:
-            ctx.match_batch_device(d_img.data_ptr(), FRAME_BYTES, B, ROWS, COLS, COLS * 3, 3, THRESHOLD,
-                                   slots[0].d_buf.data_ptr() + HDR, cap, slots[0].d_buf.data_ptr(), stream=stream.cuda_stream)
-        else:
-            ctx.match_device(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, slots[0].d_buf.data_ptr() + HDR, cap,
-                             slots[0].d_buf.data_ptr(), stream=stream.cuda_stream)
-        torch.cuda.synchronize()
-        for name, ms in ctx.timings():
+    for rep in range(prof_steps):
+        for sl in slots:
+            sl.run()
+    fence()
+    for sl in slots:
+        for name, ms in sl.ctx.timings():
             per_kernel.setdefault(name, []).append(ms)
-    ctx.set_profiling(False)
+        sl.ctx.set_profiling(False)
+    prof_steps *= len(slots)
     n_cand, refine_bytes = ctx.stats()
     coarse_bytes = ctx.coarse_bytes()
 
@@ -347,8 +353,9 @@ def main():
                      "reference case1 test image (test/case1/test.png) tiled over the whole 1024x1024 BGR canvas; ")
                     + "case1 rotation templates 0..359 (test/case1/test_templ.yaml)",
             "config": {
-                "workload": "case1 on MI355X: 1024x1024x3 frame x 360 templates per GPU (131/71 features), "
-                            "pyramid T={4,8}, threshold 90, match list gathered to the host every step",
+                "workload": "case1 on MI355X: 1024x1024x3 frames x 360 templates per GPU (131/71 features), "
+                            f"pyramid T={{4,8}}, threshold 90, {B} frame(s) per step, every frame's match list gathered "
+                            "to the host every step",
                 "templates_total": total_templates,
                 "templates_per_gpu": count,
                 "frame": [ROWS, COLS, 3],
@@ -370,9 +377,10 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": dom_bytes,
                 "avg_launch_us": kern[dom]["avg_launch_us"],
-                "note": "every kernel of a 1-Mpixel frame moves <= 10 MB from HBM (<= 1.3 us at 8 TB/s) and sits on "
-                        "the ~2.5 us launch floor; k_quantize is VALU-bound, k_similarity_coarse streams its 72 MB of "
-                        "algorithmic bytes from the L2-resident linear memories",
+                "note": "per launch = the frames of one step; figures are the mean over this kernel's launches of a step "
+                        "(k_quantize: one launch per pyramid level).  Per 1-Mpixel frame every kernel moves <= 10 MB from "
+                        "HBM (<= 1.3 us at 8 TB/s); k_quantize is VALU/latency-bound, k_similarity_coarse streams its "
+                        "72 MB per frame of algorithmic bytes from the L2-resident linear memories",
                 "whole_step": {"algorithmic_bytes": step_bytes,
                                "achieved": step_bytes / (elapsed / args.steps) / 1e9,
                                "frac": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},

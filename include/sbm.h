@@ -230,7 +230,9 @@ int sbm_similarity_local(sbm_ctx* ctx, int32_t level, int32_t template_index, in
 /* ---- measurement ---------------------------------------------------------
  * Per-kernel HIP-event timings of the last sbm_match/sbm_build_pyramid/
  * sbm_match_templates call when profiling was enabled (adds synchronisation;
- * never enabled in the throughput path). names/ms arrays hold up to cap entries. */
+ * never enabled in the throughput path). names/ms arrays hold up to cap entries.
+ * enabled = 2: the timings of successive asynchronous calls accumulate (no per-call reset) until
+ * sbm_get_timings has returned all of them -- the way to time kernels while several streams are in flight. */
 int sbm_set_profiling(sbm_ctx* ctx, int32_t enabled);
 int sbm_get_timings(sbm_ctx* ctx, const char** names, float* ms, int32_t cap, int32_t* n);
 /* Algorithmic bytes of the coarse pass for the selected templates on the

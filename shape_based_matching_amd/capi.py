@@ -339,8 +339,9 @@ class Context:
         return out
 
     # -- measurement -----------------------------------------------------------
-    def set_profiling(self, on: bool):
-        _check(lib().sbm_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, on: bool, accumulate: bool = False):
+        """accumulate: timings of successive asynchronous calls pile up until timings() reads them"""
+        _check(lib().sbm_set_profiling(self._h, (2 if accumulate else 1) if on else 0))
 
     def timings(self) -> List[Tuple[str, float]]:
         n = C.c_int32(0)

@@ -155,6 +155,7 @@ struct sbm_ctx {
 
     // profiling
     bool profiling = false;
+    bool profiling_keep = false; // enabled == 2: timings accumulate over calls until they are read
     std::vector<Timing> timings;
     std::vector<float> timing_ms;
 
@@ -865,7 +866,7 @@ int sbm_match_device(sbm_ctx* c, const void* d_img, int32_t rows, int32_t cols, 
     if (dirty) HIP_TRY(hipDeviceSynchronize());
     if (!c->graph_mode || c->profiling) {
         if (int e = ensure_geometry(c, rows, cols, channels)) return e;
-        if (c->profiling) c->clear_timings();
+        if (c->profiling && !c->profiling_keep) c->clear_timings();
         if (int e = prepare_templates(c, c->stream, threshold, cap)) return e;
         if (int e = enqueue_pyramid(c, s, (const uint8_t*)d_img, stride, (const uint8_t*)d_mask, (int32_t*)d_count)) return e;
         if (int e = enqueue_coarse(c, s, (sbm_match_rec*)d_out, cap, (int32_t*)d_count)) return e;
@@ -926,7 +927,7 @@ int sbm_match_batch_device(sbm_ctx* c, const void* d_imgs, int64_t frame_stride,
                        !c->have_thr || memcmp(&threshold, &c->thr_cached, 4) != 0 || c->foff_dirty;
     if (dirty) HIP_TRY(hipDeviceSynchronize());
     if (int e = ensure_geometry(c, rows, cols, channels, n_frames)) return e;
-    if (c->profiling) c->clear_timings();
+    if (c->profiling && !c->profiling_keep) c->clear_timings();
     if (int e = prepare_templates(c, c->stream, threshold, cap)) return e;
     if (int e = enqueue_pyramid(c, s, (const uint8_t*)d_imgs, stride, (const uint8_t*)d_mask, (int32_t*)d_counts, n_frames, frame_stride)) return e;
     if (int e = enqueue_coarse(c, s, (sbm_match_rec*)d_out, cap, (int32_t*)d_counts, n_frames)) return e;
@@ -939,7 +940,7 @@ int sbm_match_templates_device(sbm_ctx* c, float threshold, void* d_out, int64_t
     HIP_TRY(hipSetDevice(c->cfg.device_id));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     if (!c->have_thr || memcmp(&threshold, &c->thr_cached, 4) != 0 || c->foff_dirty) HIP_TRY(hipDeviceSynchronize());
-    if (c->profiling) c->clear_timings();
+    if (c->profiling && !c->profiling_keep) c->clear_timings();
     return enqueue_templates(c, s, threshold, (sbm_match_rec*)d_out, cap, (int32_t*)d_count);
 }
 
@@ -969,7 +970,7 @@ int sbm_match(sbm_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_
 {
     if (!c || (!out && cap > 0) || !n_out) return fail(SBM_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->cfg.device_id));
-    if (c->profiling) c->clear_timings();
+    if (c->profiling && !c->profiling_keep) c->clear_timings();
     if (int e = upload_image(c, img, rows, cols, stride, channels, mask)) return e;
     if (int e = prepare_templates(c, c->stream, threshold, c->cand_cap)) return e;
     if (int e = enqueue_pyramid(c, c->stream, c->d_img[0].as<uint8_t>(), cols * channels, mask ? c->d_mask[0].as<uint8_t>() : nullptr,
@@ -1007,7 +1008,7 @@ int sbm_build_pyramid(sbm_ctx* c, const uint8_t* img, int32_t rows, int32_t cols
 {
     if (!c) return fail(SBM_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->cfg.device_id));
-    if (c->profiling) c->clear_timings();
+    if (c->profiling && !c->profiling_keep) c->clear_timings();
     if (int e = upload_image(c, img, rows, cols, stride, channels, mask)) return e;
     if (int e = enqueue_pyramid(c, c->stream, c->d_img[0].as<uint8_t>(), cols * channels, mask ? c->d_mask[0].as<uint8_t>() : nullptr)) return e;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1021,7 +1022,7 @@ int sbm_set_quantized(sbm_ctx* c, int32_t level, const uint8_t* q, int32_t rows,
     if (level > c->levels_valid) return fail(SBM_ERR_STATE, "levels must be set from 0 upwards");
     HIP_TRY(hipSetDevice(c->cfg.device_id));
     if (int e = ensure_level(c, level, rows, cols)) return e;
-    if (c->profiling && level == 0) c->clear_timings();
+    if (c->profiling && !c->profiling_keep && level == 0) c->clear_timings();
     HIP_TRY(hipMemcpyAsync(c->d_quant[level].p, q, (size_t)rows * cols, hipMemcpyHostToDevice, c->stream));
     if (int e = launch_build_lm(c, c->stream, c->d_quant[level].as<uint8_t>(), rows, cols, c->cfg.T[level],
                                 c->d_lm[level].as<uint8_t>(), c->lm_stride[level]))
@@ -1066,7 +1067,7 @@ int sbm_match_templates(sbm_ctx* c, float threshold, sbm_match_rec* out, int64_t
 {
     if (!c || (!out && cap > 0) || !n_out) return fail(SBM_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->cfg.device_id));
-    if (c->profiling) c->clear_timings();
+    if (c->profiling && !c->profiling_keep) c->clear_timings();
     if (int e = enqueue_templates(c, c->stream, threshold, c->d_out.as<sbm_match_rec>(), c->cand_cap, c->d_outcount.as<int32_t>())) return e;
     int rc = fetch_results(c, c->stream, out, cap, n_out);
     if (c->profiling) collect_timings(c);
@@ -1260,7 +1261,8 @@ int sbm_set_profiling(sbm_ctx* c, int32_t enabled)
 {
     if (!c) return fail(SBM_ERR_INVALID, "null context");
     c->profiling = enabled != 0;
-    if (!c->profiling) c->clear_timings();
+    c->profiling_keep = enabled == 2;
+    c->clear_timings();
     return 0;
 }
 
@@ -1273,6 +1275,7 @@ int sbm_get_timings(sbm_ctx* c, const char** names, float* ms, int32_t cap, int3
         if (names) names[i] = c->timings[i].name;
         if (ms) ms[i] = c->timing_ms[i];
     }
+    if (c->profiling_keep && cap >= *n && *n > 0) c->clear_timings(); // read out: start the next accumulation
     return 0;
 }
 
