@@ -213,3 +213,62 @@ def test_match_batch_device(oracle, ctx_factory, case1, ch):
             stream.synchronize()
             c = d_cnt.cpu().numpy()
             assert c[0] == len(want[1]) and key(d_out.cpu().numpy()[: cap * rec].view(MATCH_DTYPE)[: c[0]]) == key(want[1])
+
+
+@pytest.mark.parametrize("T", [(4,), (8,), (4, 8, 8)])
+def test_match_batch_device_other_pyramids(oracle, ctx_factory, case1, T):
+    """the batch entry point on 1- and 3-level pyramids (single level: the coarse pass emits the records itself),
+    with a mask shared by the frames and a candidate list that overflows in one frame only"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    L = len(T)
+    ts_all = case1["templates"]
+    # templates restricted to the pyramid depth: level l of the fixture's 2-level templates, coarsest repeated for L = 3
+    from shape_based_matching_amd.templates import from_pyramids
+
+    pyrs = []
+    for t in range(300, 361, 4):
+        lv = []
+        for l in range(L):
+            src = ts_all.levels[t, min(l, 1)]
+            f = ts_all.features[src["feature_offset"]: src["feature_offset"] + src["n_features"]]
+            scale = 1 if l < 2 else 2
+            feats = np.stack([f["x"] // scale, f["y"] // scale, f["label"]], axis=1)
+            lv.append({"width": int(src["width"]) // scale, "height": int(src["height"]) // scale, "tl_x": 0, "tl_y": 0,
+                       "pyramid_level": l, "features": feats})
+        pyrs.append(lv)
+    ts = from_pyramids(pyrs, "t")
+    base = frame_of(case1)
+    frames = [base, np.roll(base, 64, axis=1), np.zeros_like(base)]
+    rows, cols = base.shape[:2]
+    mask = np.zeros((rows, cols), np.uint8)
+    mask[40:600, 60:700] = 255
+    thr = 60.0
+    ctx = ctx_factory(T=T)
+    ctx.upload_templates(ts)
+    cap = 4096
+    rec = MATCH_DTYPE.itemsize
+    stream = torch.cuda.Stream(device=dev)
+    d_imgs = torch.from_numpy(np.stack(frames)).to(dev)
+    d_mask = torch.from_numpy(mask).to(dev)
+    B = len(frames)
+    d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(B * 2, dtype=torch.int32, device=dev)
+    fs = rows * cols * 3
+    for use_mask in (False, True):
+        want = []
+        for fr in frames:
+            pyr = oracle.Pyramid.build(fr, list(T), 30.0, mask=mask if use_mask else None)
+            want.append(pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr))
+            pyr.free()
+        for _ in range(2):
+            ctx.match_batch_device(d_imgs.data_ptr(), fs, B, rows, cols, cols * 3, 3, thr, d_out.data_ptr(), cap, d_cnt.data_ptr(),
+                                   stream=stream.cuda_stream, d_mask=d_mask.data_ptr() if use_mask else 0)
+            stream.synchronize()
+            cnt = d_cnt.cpu().numpy().reshape(B, 2)
+            out = d_out.cpu().numpy().reshape(B, cap * rec)
+            for f in range(B):
+                assert cnt[f, 1] == 0 and cnt[f, 0] == len(want[f]), (T, use_mask, f, cnt[f], len(want[f]))
+                assert key(out[f].view(MATCH_DTYPE)[: cnt[f, 0]]) == key(want[f])
+        assert len(want[0]) > 0 and len(want[2]) == 0
