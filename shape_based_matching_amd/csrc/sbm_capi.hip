@@ -111,6 +111,11 @@ struct sbm_ctx {
     int levels_valid = 0; // number of levels whose linear memories are resident
     int64_t lm_stride[SBM_MAX_LEVELS]{};
     DevBuf d_img[SBM_MAX_LEVELS], d_mask[SBM_MAX_LEVELS], d_quant[SBM_MAX_LEVELS], d_lm[SBM_MAX_LEVELS];
+    // Levels that only the refinement pass reads (l < L-1) are built as ONE plane of spread bytes ("compact": an eighth
+    // of the stores and of the HBM write-back; the refinement kernel applies the response LUT itself).  The 8-plane form
+    // of such a level is materialised on demand for the stage entry points (ensure_full_lm).
+    DevBuf d_lmc[SBM_MAX_LEVELS];
+    bool lm_full[SBM_MAX_LEVELS]{}, lm_compact[SBM_MAX_LEVELS]{}; // which form of level l is current (frame 0 .. batch)
     DevBuf d_geo; // T[L], W[L], H[L] as int32 then stride[L] as int64
     bool foff_dirty = true;
     bool counters_fresh = false; // the linear-memory launch of this frame already reset the counters
@@ -268,6 +273,10 @@ int ensure_geometry(sbm_ctx* c, int rows, int cols, int channels, int frames = 1
         if (int e = c->d_quant[l].ensure(B * r * cc)) return e;
         c->d_lm[l].release(); // fresh, zeroed: the tail past T*T*W*H must read as 0
         if (int e = c->d_lm[l].ensure(B * 8 * c->lm_stride[l], true)) return e;
+        c->d_lmc[l].release();
+        if (l < c->L - 1)
+            if (int e = c->d_lmc[l].ensure(B * c->lm_stride[l], true)) return e;
+        c->lm_full[l] = c->lm_compact[l] = false;
     }
     if (B > (size_t)c->batch) { // per-frame candidate lists and counters
         if (int e = c->d_cands.ensure(B * c->cand_cap * sizeof(Cand))) return e;
@@ -293,6 +302,8 @@ int ensure_level(sbm_ctx* c, int l, int rows, int cols)
     if (int e = c->d_quant[l].ensure((size_t)rows * cols)) return e;
     c->d_lm[l].release();
     if (int e = c->d_lm[l].ensure((size_t)8 * c->lm_stride[l], true)) return e;
+    c->d_lmc[l].release();
+    c->lm_full[l] = c->lm_compact[l] = false;
     c->foff_dirty = true;
     return 0;
 }
@@ -350,6 +361,25 @@ bool lm_rows_ok(const uint8_t* d_q, int cols, int T)
     return (T == 4 || T == 8) && ((cols / T) & 3) == 0 && (cols & 15) == 0 && (((uintptr_t)d_q) & 15) == 0;
 }
 
+bool use_compact_lm()
+{
+    static const bool on = !(getenv("SBM_FULL_LM") && atoi(getenv("SBM_FULL_LM")) != 0); // tuning / A-B knob
+    return on;
+}
+
+// 8-plane linear memories of level l (frame 0) for the stage entry points, expanded from the compact plane if needed
+int ensure_full_lm(sbm_ctx* c, int l, hipStream_t s)
+{
+    if (c->lm_full[l] || !c->lm_compact[l]) return 0;
+    const int T = c->cfg.T[l];
+    const int64_t n = (int64_t)T * T * (c->cols[l] / T) * (c->rows[l] / T);
+    hipLaunchKernelGGL(k_expand_lm, dim3((unsigned)std::min<int64_t>((n / 4 + 255) / 256, 4096)), dim3(256), 0, s, c->d_lmc[l].as<uint8_t>(), n,
+                       c->d_lm[l].as<uint8_t>(), c->lm_stride[l]);
+    HIP_TRY(hipGetLastError());
+    c->lm_full[l] = true;
+    return 0;
+}
+
 int launch_build_lm(sbm_ctx* c, hipStream_t s, const uint8_t* d_q, int rows, int cols, int T, uint8_t* d_lm,
                     int64_t lm_stride)
 {
@@ -358,7 +388,7 @@ int launch_build_lm(sbm_ctx* c, hipStream_t s, const uint8_t* d_q, int rows, int
         LmArgs a;
         memset(&a, 0, sizeof a);
         a.n_levels = 1;
-        a.lv[0] = LmLevelArgs{d_q, d_lm, lm_stride, rows, cols, W, H, T, 0, 0, 0};
+        a.lv[0] = LmLevelArgs{d_q, d_lm, lm_stride, rows, cols, W, H, T, 0, 0, 0, 0};
         const int64_t items = (int64_t)rows * (W >> 2);
         SBM_LAUNCH(c, "k_build_lm", k_build_lm_rows, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
@@ -476,10 +506,13 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
                                     l == 0 ? img0_fs : (int64_t)c->rows[l] * c->cols[l] * ch))
             return e;
         if (!all_rows && frames > 1) return fail(SBM_ERR_INVALID, "batched match needs T in {4, 8} and 16-column-aligned levels");
-        if (!all_rows)
+        if (!all_rows) {
             if (int e = launch_build_lm(c, s, c->d_quant[l].as<uint8_t>(), c->rows[l], c->cols[l], c->cfg.T[l],
                                         c->d_lm[l].as<uint8_t>(), c->lm_stride[l]))
                 return e;
+            c->lm_full[l] = true;
+            c->lm_compact[l] = false;
+        }
     }
     if (all_rows) { // every level's linear memories (and the counter reset) in one launch
         LmArgs a;
@@ -488,8 +521,12 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
         int blocks = 0;
         for (int l = 0; l < c->L; ++l) {
             const int T = c->cfg.T[l], W = c->cols[l] / T, H = c->rows[l] / T;
-            a.lv[l] = LmLevelArgs{c->d_quant[l].as<uint8_t>(), c->d_lm[l].as<uint8_t>(), c->lm_stride[l], c->rows[l], c->cols[l], W, H, T, blocks,
-                                  (int64_t)c->rows[l] * c->cols[l], (int64_t)8 * c->lm_stride[l]};
+            const bool compact = l < c->L - 1 && c->d_lmc[l].p && use_compact_lm();
+            a.lv[l] = LmLevelArgs{c->d_quant[l].as<uint8_t>(), compact ? c->d_lmc[l].as<uint8_t>() : c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
+                                  c->rows[l], c->cols[l], W, H, T, blocks, (int64_t)c->rows[l] * c->cols[l],
+                                  (int64_t)(compact ? 1 : 8) * c->lm_stride[l], compact ? 1 : 0};
+            c->lm_compact[l] = compact;
+            c->lm_full[l] = !compact;
             blocks += (int)(((int64_t)c->rows[l] * (W >> 2) + 255) / 256);
         }
         if (reset_count) {
@@ -568,11 +605,17 @@ int enqueue_local(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap, 
     for (int l = L - 2; l >= 0; --l) {
         const int T = c->cfg.T[l], W = c->cols[l] / T, H = c->rows[l] / T;
         static const int local_grid = getenv("SBM_LOCAL_GRID") ? std::max(1, atoi(getenv("SBM_LOCAL_GRID"))) : 512;
-        SBM_LAUNCH(c, "k_similarity_local", k_similarity_local, dim3(frames, local_grid), dim3(64 * LOCAL_WAVES), 0, s, c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
-                           c->rows[l], c->cols[l], T, W, H, L, l, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(), c->d_foff.as<int32_t>(),
-                           c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
-                           c->d_cands.as<Cand>(), counters, (int)c->cand_cap, l == 0 ? 1 : 0, d_out, d_count, (int)cap,
-                           c->mirror_out, c->mirror_count, c->profiling ? 1 : 0, (int64_t)8 * c->lm_stride[l]);
+        const bool compact = c->lm_compact[l] && !c->lm_full[l];
+        if (!compact && !c->lm_full[l]) return fail(SBM_ERR_STATE, "linear memories of level %d are not built", l);
+#define SBM_LOCAL(COMPACT_, LM_, FS_)                                                                                               \
+        SBM_LAUNCH(c, "k_similarity_local", (k_similarity_local<COMPACT_>), dim3(frames, local_grid), dim3(64 * LOCAL_WAVES), 0, s, LM_, \
+                   c->lm_stride[l], c->rows[l], c->cols[l], T, W, H, L, l, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(),          \
+                   c->d_foff.as<int32_t>(), c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),          \
+                   c->d_cands.as<Cand>(), counters, (int)c->cand_cap, l == 0 ? 1 : 0, d_out, d_count, (int)cap, c->mirror_out,     \
+                   c->mirror_count, c->profiling ? 1 : 0, (int64_t)(FS_) * c->lm_stride[l], c->d_flabel.as<uint8_t>())
+        if (compact) SBM_LOCAL(true, c->d_lmc[l].as<uint8_t>(), 1);
+        else SBM_LOCAL(false, c->d_lm[l].as<uint8_t>(), 8);
+#undef SBM_LOCAL
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -628,6 +671,10 @@ int capture_match_graph(sbm_ctx* c, const uint8_t* d_img0, int stride0, const ui
         } else {
             rc = launch_build_lm(c, m, c->d_quant[l].as<uint8_t>(), c->rows[l], c->cols[l], c->cfg.T[l], c->d_lm[l].as<uint8_t>(), c->lm_stride[l]);
         }
+    }
+    for (int l = 0; l < L; ++l) { // the captured build is the 8-plane form at every level
+        c->lm_full[l] = true;
+        c->lm_compact[l] = false;
     }
     if (!rc) rc = enqueue_coarse(c, m, d_out, cap, d_count);
     if (!rc && forked) {
@@ -745,6 +792,7 @@ void sbm_destroy(sbm_ctx* c)
         c->d_mask[l].release();
         c->d_quant[l].release();
         c->d_lm[l].release();
+        c->d_lmc[l].release();
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -908,6 +956,10 @@ int sbm_match_device(sbm_ctx* c, const void* d_img, int32_t rows, int32_t cols, 
     }
     hit->last_use = ++c->graph_clock;
     c->levels_valid = c->L;
+    for (int l = 0; l < c->L; ++l) { // the captured build writes the 8-plane form at every level
+        c->lm_full[l] = true;
+        c->lm_compact[l] = false;
+    }
     HIP_TRY(hipGraphLaunch(hit->exec, s));
     return 0;
 }
@@ -1027,6 +1079,8 @@ int sbm_set_quantized(sbm_ctx* c, int32_t level, const uint8_t* q, int32_t rows,
     if (int e = launch_build_lm(c, c->stream, c->d_quant[level].as<uint8_t>(), rows, cols, c->cfg.T[level],
                                 c->d_lm[level].as<uint8_t>(), c->lm_stride[level]))
         return e;
+    c->lm_full[level] = true;
+    c->lm_compact[level] = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->levels_valid = std::max(c->levels_valid, level + 1);
     if (c->profiling) collect_timings(c);
@@ -1050,6 +1104,8 @@ int sbm_get_linear_memories(sbm_ctx* c, int32_t level, uint8_t* out, int64_t cap
     const int64_t need = 8 * c->lm_stride[level];
     if (cap_bytes < need) return fail(SBM_ERR_CAPACITY, "need %lld bytes", (long long)need);
     HIP_TRY(hipSetDevice(c->cfg.device_id));
+    HIP_TRY(hipDeviceSynchronize()); // the pyramid may have been built on the caller's stream
+    if (int e = ensure_full_lm(c, level, c->stream)) return e;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out, c->d_lm[level].p, (size_t)need, hipMemcpyDeviceToHost));
     return 0;
@@ -1244,6 +1300,8 @@ int sbm_similarity_local(sbm_ctx* c, int32_t level, int32_t t, int32_t cx, int32
     if (c->levels_valid <= level) return fail(SBM_ERR_STATE, "level not resident");
     HIP_TRY(hipSetDevice(c->cfg.device_id));
     if (int e = ensure_foff(c, c->stream)) return e;
+    HIP_TRY(hipDeviceSynchronize());
+    if (int e = ensure_full_lm(c, level, c->stream)) return e;
     const int T = c->cfg.T[level], W = c->cols[level] / T, H = c->rows[level] / T;
     DevBuf d;
     if (int e = d.ensure(512)) return e;

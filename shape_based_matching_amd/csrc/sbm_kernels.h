@@ -797,7 +797,8 @@ __device__ __forceinline__ uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t 
 
 template <int T>
 __device__ __forceinline__ void build_lm_rows_item(const uint8_t* __restrict__ q, int rows, int cols, int W, int H,
-                                                   uint8_t* __restrict__ lm, int64_t lm_stride, int64_t item)
+                                                   uint8_t* __restrict__ lm, int64_t lm_stride, int64_t item,
+                                                   bool compact)
 {
     constexpr int NQ = T / 4 * 4; // dwords of own pixels per lane (4 cells * T px / 4)
     const int lanes_per_row = W >> 2;
@@ -858,8 +859,12 @@ __device__ __forceinline__ void build_lm_rows_item(const uint8_t* __restrict__ q
         const uint32_t p23 = perm_b32(d3, d2, 0x00000c0cu | ((4 + b) << 24) | (b << 16)); // {0, 0, d2.b, d3.b}
         const uint32_t sp = p01 | p23;
         const int64_t dst = (int64_t)(ty * T + tx) * WH + cell;
+        if (compact) { // one plane of spread bytes: the reader applies the response LUT for its own orientation
+            *(uint32_t*)(lm + dst) = sp;
+        } else {
 #pragma unroll
-        for (int o = 0; o < 8; ++o) *(uint32_t*)(lm + o * lm_stride + dst) = response4(sp, o);
+            for (int o = 0; o < 8; ++o) *(uint32_t*)(lm + o * lm_stride + dst) = response4(sp, o);
+        }
     }
 }
 
@@ -872,6 +877,8 @@ struct LmLevelArgs {
     int32_t rows, cols, W, H, T;
     int32_t block_begin; // first block of this level
     int64_t q_fs, lm_fs; // bytes from one frame of a batch to the next
+    int32_t compact;     // 1: lm is ONE plane [T*T][W*H] of spread bytes (a level that only the refinement pass
+                         // reads): 1/8 of the stores and of the HBM write-back
 };
 struct LmArgs {
     LmLevelArgs lv[SBM_MAX_LEVELS];
@@ -895,8 +902,21 @@ __global__ __launch_bounds__(256) void k_build_lm_rows(const LmArgs a)
     const int64_t item = (int64_t)((int)blockIdx.x - p.block_begin) * 256 + threadIdx.x;
     const uint8_t* q = p.q + frame * p.q_fs;
     uint8_t* lm = p.lm + frame * p.lm_fs;
-    if (p.T == 4) build_lm_rows_item<4>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item);
-    else build_lm_rows_item<8>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item);
+    if (p.T == 4) build_lm_rows_item<4>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact != 0);
+    else build_lm_rows_item<8>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact != 0);
+}
+
+// compact plane (spread bytes) -> the 8 response planes, for the stage entry points that hand out or read a
+// full linear memory of a refinement-only level
+__global__ __launch_bounds__(256) void k_expand_lm(const uint8_t* __restrict__ lmc, int64_t n_bytes,
+                                                   uint8_t* __restrict__ lm, int64_t lm_stride)
+{
+    const int64_t n4 = n_bytes >> 2; // T*T*W*H is a multiple of 16
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const uint32_t v = ((const uint32_t*)lmc)[i];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) *(uint32_t*)(lm + o * lm_stride + 4 * i) = response4(v, o);
+    }
 }
 
 // unfused single-function kernels (stage entry points / parity tests)
@@ -983,12 +1003,16 @@ constexpr int FB16 = 8;                 // same for the 16-byte variant (coarse 
 // end of the range reads zero bytes from the linear memories' zero tail.
 // Packed-u8 partial sums are carry-free for <= 63 addends (63 * 4 = 252) and
 // are flushed into two packed-u16 words before that.
+// COMPACT: lm is the single spread plane of a refinement-only level; the feature's orientation plane offset
+// (label * lm_stride, part of foff) is taken out again and the response LUT is applied to the loaded bytes.
+template <bool COMPACT = false>
 __device__ __forceinline__ void accumulate_features(const uint8_t* __restrict__ lm,
                                                     const uint32_t* __restrict__ fxy,
                                                     const int32_t* __restrict__ foff, int f0, int count,
                                                     int rows, int cols, int ox, int oy, int lane_off,
                                                     const uint8_t* __restrict__ zero_addr, int zero_lane_off,
-                                                    uint32_t& lo, uint32_t& hi)
+                                                    uint32_t& lo, uint32_t& hi,
+                                                    const uint8_t* __restrict__ flabel = nullptr, int lm_stride = 0)
 {
     const int lane = threadIdx.x & 63;
     const uint8_t* p_ok = lm + lane_off;
@@ -999,11 +1023,15 @@ __device__ __forceinline__ void accumulate_features(const uint8_t* __restrict__ 
     count = __builtin_amdgcn_readfirstlane(count); // wave-uniform by contract: keep the loop control scalar
     f0 = __builtin_amdgcn_readfirstlane(f0);
     for (int b = 0; b < count; b += 64) {
-        int sel = -1;
+        int sel = -1, lab = 0;
         if (b + lane < count) {
             const uint32_t xy = fxy[f0 + b + lane];
             const int x = (int)(xy & 0xffff) + ox, y = (int)(xy >> 16) + oy;
             if (x >= 0 && y >= 0 && x < cols && y < rows) sel = foff[f0 + b + lane];
+            if (COMPACT) {
+                lab = flabel[f0 + b + lane];
+                if (sel >= 0) sel -= lab * lm_stride;
+            }
         }
         const int nb = count - b < 64 ? count - b : 64;
         // straight-line batches (no branches between the loads of a batch, so all of a batch's
@@ -1015,6 +1043,10 @@ __device__ __forceinline__ void accumulate_features(const uint8_t* __restrict__ 
             for (int k = 0; k < n; ++k) {
                 const int o = __builtin_amdgcn_readlane(sel, (u + k) & 63);
                 v[k] = ld_u32_any(o >= 0 ? p_ok + o : p_zero);
+            }
+            if (COMPACT) {
+#pragma unroll
+                for (int k = 0; k < n; ++k) v[k] = response4(v[k], __builtin_amdgcn_readlane(lab, (u + k) & 63));
             }
 #pragma unroll
             for (int k = 0; k < n; ++k) acc += v[k];
@@ -1293,20 +1325,23 @@ __device__ __forceinline__ void publish_counts(int32_t* __restrict__ counters, i
 // LOCAL_WAVES waves each take a contiguous slice of the features and the partial
 // sums meet in LDS.  Result (packed u16) valid in wave 0.
 constexpr int LOCAL_WAVES = 16;
+template <bool COMPACT = false>
 __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int64_t lm_stride, const DevTL tl,
                                             const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
                                             int rows, int cols, int W, int H, int T, int ox, int oy,
-                                            uint32_t (*s_part)[2][64], uint32_t& lo, uint32_t& hi)
+                                            uint32_t (*s_part)[2][64], uint32_t& lo, uint32_t& hi,
+                                            const uint8_t* __restrict__ flabel = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane >> 2, c4 = (lane & 3) * 4;
     const int delta = (oy / T) * W + ox / T + r * W + c4;
-    const uint8_t* zero_addr = lm + 7 * lm_stride + (int64_t)T * T * W * H;
+    const uint8_t* zero_addr = lm + (COMPACT ? 0 : 7) * lm_stride + (int64_t)T * T * W * H;
     const int chunk = (tl.nf + LOCAL_WAVES - 1) / LOCAL_WAVES;
     const int f0 = wave * chunk;
     int cnt = tl.nf - f0;
     cnt = cnt < 0 ? 0 : (cnt > chunk ? chunk : cnt);
-    accumulate_features(lm, fxy + tl.feat_off, foff + tl.feat_off, f0, cnt, rows, cols, ox, oy, delta, zero_addr, 0, lo, hi);
+    accumulate_features<COMPACT>(lm, fxy + tl.feat_off, foff + tl.feat_off, f0, cnt, rows, cols, ox, oy, delta, zero_addr, 0, lo, hi,
+                                 COMPACT ? flabel + tl.feat_off : nullptr, (int)lm_stride);
     s_part[wave][0][lane] = lo;
     s_part[wave][1][lane] = hi;
     __syncthreads();
@@ -1323,6 +1358,7 @@ __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int6
 
 // One block (LOCAL_WAVES waves) per candidate: refine at level l (line2Dup.cpp:1233-1287),
 // apply the per-level filter (:1290-1292); at level 0 emit the final Match record.
+template <bool COMPACT>
 __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
     const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int l,
     const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
@@ -1330,7 +1366,7 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
     const int32_t* __restrict__ template_id, Cand* __restrict__ cands, int32_t* __restrict__ counters,
     int cand_cap, int is_last, sbm_match_rec* __restrict__ out, int32_t* __restrict__ out_count,
     int out_cap, sbm_match_rec* __restrict__ mirror_out, int32_t* __restrict__ mirror_count, int collect_stats,
-    int64_t lm_fs)
+    int64_t lm_fs, const uint8_t* __restrict__ flabel)
 {
     // grid = (frames, candidate slots): the frame is the FAST grid dimension, so the blocks dispatched first are
     // the low slots of every frame -- the ones that have a candidate -- and the idle slots come last
@@ -1369,7 +1405,7 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
         y = y > max_y ? max_y : y;
         const int ox = (x / T - 8) * T, oy = (y / T - 8) * T;
         uint32_t lo, hi;
-        local_patch(lm, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi);
+        local_patch<COMPACT>(lm, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi, flabel);
         if (wave != 0) continue;
         // first maximum in row-major order, strict '>' from 0 (:1265-1282): maximise (raw, -position)
         uint32_t best = 0;
