@@ -246,7 +246,7 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
     __shared__ __attribute__((aligned(16))) uint32_t s_w[QQ_R][QH_W]; // vote word 1 << 4*label per pixel
     __shared__ uint32_t s_st[QQ_R][QH_W / 4];      // u8 x4: non-zero = magnitude above the weak threshold
     __shared__ uint32_t s_pyr[QT_R / 2][QT_C / 2 * CH / 4]; // pyrDown of the tile, interleaved channels, as dwords
-    __shared__ uint32_t s_nonflat;
+    __shared__ __attribute__((aligned(16))) uint32_t s_nonflat[16]; // per wave: it loaded a word that differs from the tile's first pixel
     const int tid = threadIdx.x;
     const int R0 = blockIdx.y * QT_R, C0 = blockIdx.x * QT_C;
     const bool interior = R0 >= 5 && R0 + QT_R + 5 <= rows && C0 >= 8 && C0 + QT_C + 8 <= cols;
@@ -254,11 +254,19 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
     // every kernel argument is fetched here, with the first ones: a scalar load issued in the middle of the
     // tile costs a scalar-cache round trip on the critical path of its phase
     asm volatile("" ::"s"(thr_sq), "s"(out), "s"(mask), "s"(pyr_out), "s"(mag_out), "s"(ori_out), "s"(stride));
-    if (tid == 0) s_nonflat = 0;
 
     // ---- A: source tile -> planar LDS (rows clamped; a 4-pixel group that sticks out of the image
     //         left or right takes the per-byte clamped path = BORDER_REPLICATE) ----
     const bool whole_groups = cols >= 4 && (cols & 3) == 0; // 4-pixel groups lie entirely inside or outside the image
+    // flat-tile test, folded into the load: every word of the tile against the tile's first pixel
+    const bool flat_check = !WITH_FLOAT && thr_sq >= 0.f;
+    uint32_t ref[CH];
+    bool nonflat = false;
+    if (flat_check) {
+        const uint8_t* p0 = img + (size_t)clampi(R0 - 5, 0, rows - 1) * stride + (size_t)clampi(C0 - 8, 0, cols - 1) * CH;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) ref[k] = (uint32_t)p0[k] * 0x01010101u;
+    }
     for (int it = tid; it < QS_R * (QS_W / 4); it += QN) {
         const int r = it / (QS_W / 4), g = it - r * (QS_W / 4);
         const int gr = clampi(R0 - 5 + r, 0, rows - 1);
@@ -283,6 +291,7 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
                 if (c < 0) w[k] = (w[k] & 0xffu) * 0x01010101u;
                 if (c >= cols) w[k] = (w[k] >> 24) * 0x01010101u;
                 s_src[k][r][g] = w[k];
+                if (flat_check) nonflat = nonflat || w[k] != ref[k];
             }
         } else {
 #pragma unroll
@@ -291,8 +300,13 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
 #pragma unroll
                 for (int m = 0; m < 4; ++m) w |= (uint32_t)rowp[clampi(c + m, 0, cols - 1) * CH + k] << (8 * m);
                 s_src[k][r][g] = w;
+                if (flat_check) nonflat = nonflat || w != ref[k];
             }
         }
+    }
+    if (flat_check) {
+        const bool wave_nonflat = __builtin_amdgcn_ballot_w64(nonflat) != 0;
+        if ((tid & 63) == 0) s_nonflat[tid >> 6] = wave_nonflat ? 1u : 0u;
     }
     lds_barrier();
     QSTAMP(1)
@@ -302,16 +316,14 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
     //      the reference's own demo pads the frame with 250 black pixels, test.cpp:344-347); the pyrDown of
     //      a constant tile is the same constant.  WITH_FLOAT keeps the full path so that magnitude / angle
     //      are written everywhere. ----
-    if (!WITH_FLOAT && thr_sq >= 0.f) {
-        bool flat = true;
+    if (flat_check) {
+        uint32_t any = 0;
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            const uint32_t ref = (s_src[k][0][0] & 0xffu) * 0x01010101u;
-            for (int it = tid; it < QS_R * (QS_W / 4); it += QN) flat = flat && (s_src[k][it / (QS_W / 4)][it % (QS_W / 4)] == ref);
+        for (int w4 = 0; w4 < QN / 64 / 4; ++w4) {
+            const uint4 f = *(const uint4*)&s_nonflat[4 * w4];
+            any |= f.x | f.y | f.z | f.w;
         }
-        if (!flat) s_nonflat = 1; // benign race: every writer stores the same value
-        lds_barrier();
-        if (s_nonflat == 0) {
+        if (any == 0) {
             const int er = tid >> 4, g = tid & 15;
             const int r = R0 + er;
             if (tid < 256 && r < rows) {
