@@ -267,33 +267,55 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
 #pragma unroll
         for (int k = 0; k < CH; ++k) ref[k] = (uint32_t)p0[k] * 0x01010101u;
     }
-    for (int it = tid; it < QS_R * (QS_W / 4); it += QN) {
-        const int r = it / (QS_W / 4), g = it - r * (QS_W / 4);
-        const int gr = clampi(R0 - 5 + r, 0, rows - 1);
-        const int c = C0 - 8 + 4 * g;
-        const uint8_t* rowp = img + (size_t)gr * stride;
-        if (whole_groups) {
-            // a group outside the image replicates the first / last pixel of the row: load the nearest inside
-            // group and broadcast its edge byte (one memory round trip for every lane, no divergent byte path)
-            const uint8_t* p = rowp + (size_t)clampi(c, 0, cols - 4) * CH;
-            uint32_t w[CH];
-            if (CH == 1) {
-                w[0] = ld_u32_any(p);
-            } else {
-                const uint32_t d0 = ld_u32_any(p), d1 = ld_u32_any(p + 4), d2 = ld_u32_any(p + 8);
-                // 12 interleaved bytes b0..b11 -> channel k = {b[k], b[k+3], b[k+6], b[k+9]}
-                w[0] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c060300u), 0x05020100u);
-                w[1 % CH] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c070401u), 0x06020100u);
-                w[2 % CH] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c0c0502u), 0x07040100u);
-            }
+    constexpr int A_ITEMS = QS_R * (QS_W / 4), A_ROUNDS = (A_ITEMS + QN - 1) / QN;
+    if (whole_groups) {
+        // A group outside the image replicates the first / last pixel of the row: load the nearest inside group and
+        // broadcast its edge byte (one memory round trip for every lane, no divergent byte path).  The loads of every
+        // round are issued before any of them is consumed: 520 items on 512 threads must not cost two round trips.
+        uint32_t d[A_ROUNDS][CH == 1 ? 1 : 3];
 #pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                if (c < 0) w[k] = (w[k] & 0xffu) * 0x01010101u;
-                if (c >= cols) w[k] = (w[k] >> 24) * 0x01010101u;
-                s_src[k][r][g] = w[k];
-                if (flat_check) nonflat = nonflat || w[k] != ref[k];
+        for (int rd = 0; rd < A_ROUNDS; ++rd) {
+            const int it = tid + rd * QN;
+            if (it < A_ITEMS) {
+                const int r = it / (QS_W / 4), g = it - r * (QS_W / 4);
+                const uint8_t* p = img + (size_t)clampi(R0 - 5 + r, 0, rows - 1) * stride + (size_t)clampi(C0 - 8 + 4 * g, 0, cols - 4) * CH;
+                d[rd][0] = ld_u32_any(p);
+                if (CH > 1) {
+                    d[rd][1 % (CH == 1 ? 1 : 3)] = ld_u32_any(p + 4);
+                    d[rd][2 % (CH == 1 ? 1 : 3)] = ld_u32_any(p + 8);
+                }
             }
-        } else {
+        }
+#pragma unroll
+        for (int rd = 0; rd < A_ROUNDS; ++rd) {
+            const int it = tid + rd * QN;
+            if (it < A_ITEMS) {
+                const int r = it / (QS_W / 4), g = it - r * (QS_W / 4);
+                const int c = C0 - 8 + 4 * g;
+                uint32_t w[CH];
+                if (CH == 1) {
+                    w[0] = d[rd][0];
+                } else {
+                    const uint32_t d0 = d[rd][0], d1 = d[rd][1 % (CH == 1 ? 1 : 3)], d2 = d[rd][2 % (CH == 1 ? 1 : 3)];
+                    // 12 interleaved bytes b0..b11 -> channel k = {b[k], b[k+3], b[k+6], b[k+9]}
+                    w[0] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c060300u), 0x05020100u);
+                    w[1 % CH] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c070401u), 0x06020100u);
+                    w[2 % CH] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c0c0502u), 0x07040100u);
+                }
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    if (c < 0) w[k] = (w[k] & 0xffu) * 0x01010101u;
+                    if (c >= cols) w[k] = (w[k] >> 24) * 0x01010101u;
+                    s_src[k][r][g] = w[k];
+                    if (flat_check) nonflat = nonflat || w[k] != ref[k];
+                }
+            }
+        }
+    } else {
+        for (int it = tid; it < A_ITEMS; it += QN) {
+            const int r = it / (QS_W / 4), g = it - r * (QS_W / 4);
+            const int c = C0 - 8 + 4 * g;
+            const uint8_t* rowp = img + (size_t)clampi(R0 - 5 + r, 0, rows - 1) * stride;
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 uint32_t w = 0;

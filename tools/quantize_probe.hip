@@ -27,6 +27,7 @@ int main(int argc, char** argv)
     std::vector<uint8_t> img((size_t)rows * cols * 3);
     srand(7);
     for (auto& b : img) b = (uint8_t)(rand() >> 7);
+    if (getenv("PROBE_BLACK")) std::fill(img.begin(), img.end(), (uint8_t)0); // every tile takes the flat-tile exit
     uint8_t *d_img, *d_out, *d_pyr;
     CK(hipMalloc(&d_img, img.size())); CK(hipMalloc(&d_out, (size_t)rows * cols)); CK(hipMalloc(&d_pyr, img.size() / 4));
     CK(hipMemcpy(d_img, img.data(), img.size(), hipMemcpyHostToDevice));
