@@ -607,15 +607,20 @@ int enqueue_local(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap, 
         static const int local_grid = getenv("SBM_LOCAL_GRID") ? std::max(1, atoi(getenv("SBM_LOCAL_GRID"))) : 512;
         const bool compact = c->lm_compact[l] && !c->lm_full[l];
         if (!compact && !c->lm_full[l]) return fail(SBM_ERR_STATE, "linear memories of level %d are not built", l);
+        static const int local_waves = getenv("SBM_LOCAL_WAVES") ? atoi(getenv("SBM_LOCAL_WAVES")) : 0; // tuning knob: 4 or 16
+        const bool small_blocks = local_waves ? local_waves == 4 : frames >= 4;
 #define SBM_LOCAL(COMPACT_, LM_, FS_)                                                                                               \
-        SBM_LAUNCH(c, "k_similarity_local", (k_similarity_local<COMPACT_>), dim3(frames, local_grid), dim3(64 * LOCAL_WAVES), 0, s, LM_, \
+        if (small_blocks) SBM_LOCAL_LW(COMPACT_, LM_, FS_, 4); else SBM_LOCAL_LW(COMPACT_, LM_, FS_, LOCAL_WAVES)
+#define SBM_LOCAL_LW(COMPACT_, LM_, FS_, LW_)                                                                                       \
+        SBM_LAUNCH(c, "k_similarity_local", (k_similarity_local<COMPACT_, LW_>), dim3(frames, local_grid), dim3(64 * LW_), 0, s, LM_, \
                    c->lm_stride[l], c->rows[l], c->cols[l], T, W, H, L, l, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(),          \
                    c->d_foff.as<int32_t>(), c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),          \
                    c->d_cands.as<Cand>(), counters, (int)c->cand_cap, l == 0 ? 1 : 0, d_out, d_count, (int)cap, c->mirror_out,     \
                    c->mirror_count, c->profiling ? 1 : 0, (int64_t)(FS_) * c->lm_stride[l], c->d_flabel.as<uint8_t>())
-        if (compact) SBM_LOCAL(true, c->d_lmc[l].as<uint8_t>(), 1);
-        else SBM_LOCAL(false, c->d_lm[l].as<uint8_t>(), 8);
+        if (compact) { SBM_LOCAL(true, c->d_lmc[l].as<uint8_t>(), 1); }
+        else { SBM_LOCAL(false, c->d_lm[l].as<uint8_t>(), 8); }
 #undef SBM_LOCAL
+#undef SBM_LOCAL_LW
         HIP_TRY(hipGetLastError());
     }
     return 0;

@@ -1359,7 +1359,7 @@ __device__ __forceinline__ void publish_counts(int32_t* __restrict__ counters, i
 // LOCAL_WAVES waves each take a contiguous slice of the features and the partial
 // sums meet in LDS.  Result (packed u16) valid in wave 0.
 constexpr int LOCAL_WAVES = 16;
-template <bool COMPACT = false>
+template <bool COMPACT = false, int LW = LOCAL_WAVES>
 __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int64_t lm_stride, const DevTL tl,
                                             const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
                                             int rows, int cols, int W, int H, int T, int ox, int oy,
@@ -1370,7 +1370,7 @@ __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int6
     const int r = lane >> 2, c4 = (lane & 3) * 4;
     const int delta = (oy / T) * W + ox / T + r * W + c4;
     const uint8_t* zero_addr = lm + (COMPACT ? 0 : 7) * lm_stride + (int64_t)T * T * W * H;
-    const int chunk = (tl.nf + LOCAL_WAVES - 1) / LOCAL_WAVES;
+    const int chunk = (tl.nf + LW - 1) / LW;
     const int f0 = wave * chunk;
     int cnt = tl.nf - f0;
     cnt = cnt < 0 ? 0 : (cnt > chunk ? chunk : cnt);
@@ -1382,7 +1382,7 @@ __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int6
     if (wave == 0) {
         lo = hi = 0;
 #pragma unroll
-        for (int w = 0; w < LOCAL_WAVES; ++w) {
+        for (int w = 0; w < LW; ++w) {
             lo += s_part[w][0][lane];
             hi += s_part[w][1][lane];
         }
@@ -1392,8 +1392,10 @@ __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int6
 
 // One block (LOCAL_WAVES waves) per candidate: refine at level l (line2Dup.cpp:1233-1287),
 // apply the per-level filter (:1290-1292); at level 0 emit the final Match record.
-template <bool COMPACT>
-__global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
+// LW waves per candidate: 16 when a launch has few candidates per CU (their latency is the launch's duration), 4 for
+// a batch of frames (4x as many candidates in flight, idle slots 4x cheaper to dispatch).
+template <bool COMPACT, int LW>
+__global__ __launch_bounds__(64 * LW) void k_similarity_local(
     const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int l,
     const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
     const int32_t* __restrict__ raw_keep, const int32_t* __restrict__ class_idx,
@@ -1415,7 +1417,7 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
         if (mirror_out) mirror_out += frame * out_cap;
         if (mirror_count) mirror_count += frame * 2;
     }
-    __shared__ uint32_t s_part[LOCAL_WAVES][2][64];
+    __shared__ uint32_t s_part[LW][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // the candidate count and this block's first candidate are fetched together (the record is read
     // speculatively: the buffer always exists, the count decides whether it is used)
@@ -1439,7 +1441,7 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local(
         y = y > max_y ? max_y : y;
         const int ox = (x / T - 8) * T, oy = (y / T - 8) * T;
         uint32_t lo, hi;
-        local_patch<COMPACT>(lm, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi, flabel);
+        local_patch<COMPACT, LW>(lm, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi, flabel);
         if (wave != 0) continue;
         // first maximum in row-major order, strict '>' from 0 (:1265-1282): maximise (raw, -position)
         uint32_t best = 0;
