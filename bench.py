@@ -13,7 +13,7 @@ Workload (BASELINE.json configs[1], "case1 on 1x MI355X"): the reference's
 case1 test image centred on a 1024 x 1024 BGR canvas, 360 case1 rotation
 templates (131 / 71 features) per GPU, pyramid {4, 8}, threshold 90.  With N
 GPUs the template set is N x 360 (weak scaling), sharded by contiguous ranges.
---batch frames per step (default 8: sbm_match_batch_device launches every kernel
+--batch frames per step (default 16: sbm_match_batch_device launches every kernel
 once for the whole batch; frame b is the workload frame shifted 8*b columns) and
 --inflight independent slots (contexts + streams, default 2) used round-robin;
 --batch 1 --inflight 1 is strictly one frame at a time (sbm_match_device).
@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="frames in flight per GPU: independent engine contexts + HIP streams used round-robin "
                          "(1 = strictly one frame at a time; the single-stream figure is always reported too)")
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=16,
                     help="frames per step: a step is one sbm_match_batch_device call over this many frames (distinct "
                          "horizontal shifts of the workload frame); 1 = one sbm_match_device call per step")
     ap.add_argument("--frame", choices=("case1", "tiled"), default="case1",
@@ -283,22 +283,19 @@ def main():
     matches = np.concatenate([recs[r, 0, : counts[r, 0, 0]] for r in range(world)])
     n_matches = len(capi.canonicalize(matches))
 
-    # per-kernel durations: a second pass of the same steps, in the same configuration as the timed region (every
-    # slot, round-robin, nothing synchronised in between), with the dispatch packets' own start/stop timestamps
+    # per-kernel durations: a second pass of the same steps on ONE slot (its stream runs the kernels back to back with
+    # nothing synchronised in between, so a kernel's duration is its own: with two slots the kernels of the two steps
+    # overlap on the GPU and stretch each other), timed with the dispatch packets' own start/stop timestamps
     # (hipExtLaunchKernelGGL events on the launch stream); kept out of the timed region above
-    for sl in slots:
-        sl.ctx.set_profiling(True, accumulate=True)
+    slots[0].ctx.set_profiling(True, accumulate=True)
     per_kernel = {}
     prof_steps = min(args.steps, 50)
     for rep in range(prof_steps):
-        for sl in slots:
-            sl.run()
+        slots[0].run()
     fence()
-    for sl in slots:
-        for name, ms in sl.ctx.timings():
-            per_kernel.setdefault(name, []).append(ms)
-        sl.ctx.set_profiling(False)
-    prof_steps *= len(slots)
+    for name, ms in slots[0].ctx.timings():
+        per_kernel.setdefault(name, []).append(ms)
+    slots[0].ctx.set_profiling(False)
     n_cand, refine_bytes = ctx.stats()
     coarse_bytes = ctx.coarse_bytes()
 

@@ -9,13 +9,22 @@ for a 3 MiB frame)."""
 import collections, csv, json, sys
 
 def per_kernel(path, counter):
-    acc = collections.defaultdict(list)
+    """mean per launch over the launches of the timed steps: bench.py also issues a few single-frame launches
+    (verification), so per kernel only the work-group count that occurs most often is kept, and for a kernel with
+    several launches per step (k_quantize: one per level) the mean is taken over those"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter:
             continue
-        name = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0].replace('sbm::', '')
-        acc[name].append(float(r['Counter_Value']))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+        full = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('sbm::', '')
+        name = full.split('<')[0]
+        acc[name][(full, r.get('Grid_Size', ''))].append(float(r['Counter_Value']))
+    out = {}
+    for name, groups in acc.items():
+        most = max(len(v) for v in groups.values())
+        vals = [x for v in groups.values() if len(v) * 2 >= most for x in v]  # the step's launches (all levels)
+        out[name] = sum(vals) / len(vals)
+    return out
 
 fetch = per_kernel(sys.argv[1], 'FETCH_SIZE')
 write = per_kernel(sys.argv[2], 'WRITE_SIZE')
