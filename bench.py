@@ -94,6 +94,9 @@ def cpu_baseline(ts, frame, budget_s: float = 12.0):
         "sample": f"{reps} full match() calls of the bench frame with {ts.n_templates} templates "
                   f"({per * 1e3:.1f} ms each, {n} raw matches); host has {ncpu} logical cores",
         "ms_per_match": per * 1e3,
+        # both ways of running the reference's OpenMP template loop (always report both)
+        "ms_per_match_1_thread": t1 * 1e3,
+        "ms_per_match_all_threads": tn * 1e3,
     }
 
 
@@ -361,6 +364,10 @@ def main():
                 "us_per_frame": elapsed / args.steps / B * 1e6,
                 "frames_in_flight": len(slots) * B,
                 ("ms_per_step_one_frame_at_a_time" if B == 1 else "ms_per_step_one_batch_at_a_time"): single_ms,
+                # SURVEY 8d's two times per frame, from the per-kernel pass (kernels alone on one stream):
+                # t_match = all five kernels, t_templ = the template loop (coarse + refinement) only
+                "t_match_kernels_us_per_frame": sum(v["ms_per_step"] for v in kern.values()) * 1e3 / B,
+                "t_templ_kernels_us_per_frame": sum(v["ms_per_step"] for k, v in kern.items() if k.startswith("k_similarity")) * 1e3 / B,
                 "matches_distinct": n_matches,
                 "coarse_candidates_rank0": n_cand,
             },
