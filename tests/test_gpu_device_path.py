@@ -272,3 +272,93 @@ def test_match_batch_device_other_pyramids(oracle, ctx_factory, case1, T):
                 assert cnt[f, 1] == 0 and cnt[f, 0] == len(want[f]), (T, use_mask, f, cnt[f], len(want[f]))
                 assert key(out[f].view(MATCH_DTYPE)[: cnt[f, 0]]) == key(want[f])
         assert len(want[0]) > 0 and len(want[2]) == 0
+
+
+def test_context_state_sequences(oracle, ctx_factory, case1):
+    """one context, a seeded random walk over its entry points (single frame, batch, host path, stage reads, caller-made
+    orientation maps, geometry / threshold / template-selection changes): every result against the oracle.  Guards the
+    per-level bookkeeping (compact vs 8-plane linear memories, batch capacity, cached thresholds and feature offsets)."""
+    import zlib
+
+    import torch
+
+    dev = torch.device("cuda", 0)
+    ts = case1["templates"].subset(range(296, 361, 4))
+    base = frame_of(case1)                                   # 640 x 768
+    small = np.ascontiguousarray(base[64:64 + 512, 96:96 + 576])  # 512 x 576
+    geos = {"A": base, "B": small, "Ag": np.ascontiguousarray(base[:, :, 1])}
+    ctx = ctx_factory()
+    ctx.upload_templates(ts)
+    cap, rec = 1024, MATCH_DTYPE.itemsize
+    stream = torch.cuda.Stream(device=dev)
+    d_out = torch.zeros(4 * cap * rec, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(8, dtype=torch.int32, device=dev)
+    rs = np.random.RandomState(2024)
+    pyr_cache = {}
+
+    def want(img, thr):
+        k = (img.shape, zlib.crc32(np.ascontiguousarray(img).tobytes()), thr)
+        if k not in pyr_cache:
+            p = oracle.Pyramid.build(img, [4, 8], 30.0)
+            pyr_cache[k] = (p, p.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr))
+        return pyr_cache[k]
+
+    n_checked = 0
+    for step in range(40):
+        op = rs.randint(0, 6)
+        g = ("A", "B", "Ag")[rs.randint(0, 3)]
+        img = geos[g]
+        ch = 1 if img.ndim == 2 else 3
+        thr = (88.0, 75.0)[rs.randint(0, 2)]
+        rows, cols = img.shape[:2]
+        if op == 0:  # host path
+            pyr, w = want(img, thr)
+            assert key(ctx.match(img, thr)) == key(w), (step, "match", g, thr)
+        elif op == 1:  # single frame, device path
+            d_img = torch.from_numpy(img).to(dev)
+            ctx.match_device(d_img.data_ptr(), rows, cols, cols * ch, ch, thr, d_out.data_ptr(), cap, d_cnt.data_ptr(), stream=stream.cuda_stream)
+            stream.synchronize()
+            n = int(d_cnt.cpu().numpy()[0])
+            pyr, w = want(img, thr)
+            assert key(d_out.cpu().numpy()[: cap * rec].view(MATCH_DTYPE)[:n]) == key(w), (step, "device", g, thr)
+        elif op == 2:  # batch of 1..4 frames (shifted copies)
+            B = int(rs.randint(1, 5))
+            frames = [np.roll(img, 16 * b, axis=1) for b in range(B)]
+            d_imgs = torch.from_numpy(np.stack(frames)).to(dev)
+            ctx.match_batch_device(d_imgs.data_ptr(), rows * cols * ch, B, rows, cols, cols * ch, ch, thr, d_out.data_ptr(), cap,
+                                   d_cnt.data_ptr(), stream=stream.cuda_stream)
+            stream.synchronize()
+            cnt = d_cnt.cpu().numpy().reshape(4, 2)
+            out = d_out.cpu().numpy().reshape(4, cap * rec)
+            for b in range(B):
+                pyr, w = want(frames[b], thr)
+                assert key(out[b].view(MATCH_DTYPE)[: cnt[b, 0]]) == key(w), (step, "batch", g, thr, b)
+        elif op == 3:  # read the pyramid state of the last frame-0 build back (expands compact levels)
+            ctx.build_pyramid(img)
+            pyr = oracle.Pyramid.build(img, [4, 8], 30.0)
+            for l in range(2):
+                assert np.array_equal(ctx.get_quantized(l), pyr.quantized(l))
+                assert np.array_equal(ctx.get_linear_memories(l), pyr.lm(l)), (step, "lm", g, l)
+            t = int(rs.randint(0, ts.n_templates))
+            for l in range(2):
+                cx, cy = int(rs.randint(40, cols - 40)) >> l, int(rs.randint(40, rows - 40)) >> l
+                assert np.array_equal(ctx.similarity_local(l, t, cx, cy), pyr.similarity_local(ts.levels[t, l], ts.features, l, cx, cy))
+            assert key(ctx.match_templates(thr)) == key(pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr))
+            pyr.free()
+        elif op == 4:  # caller-made orientation maps, template loop only
+            pyr, _ = want(img, thr)
+            for l in range(2):
+                ctx.set_quantized(l, pyr.quantized(l))
+            assert key(ctx.match_templates(thr)) == key(pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr)), (step, "set_q", g)
+        else:  # template selection: a sub-range, then everything again
+            first, count = int(rs.randint(0, ts.n_templates - 3)), 3
+            ctx.select_range(first, count)
+            sub = ts.subset(range(first, first + count))
+            pyr, _ = want(img, thr)
+            w = pyr.match(sub.levels, sub.features, sub.class_idx, sub.template_id, thr)
+            assert key(ctx.match(img, thr)) == key(w), (step, "range", g, first)
+            ctx.select_range(0, ts.n_templates)
+        n_checked += 1
+    assert n_checked == 40
+    for p, _ in pyr_cache.values():
+        p.free()
