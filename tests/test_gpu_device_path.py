@@ -362,3 +362,47 @@ def test_context_state_sequences(oracle, ctx_factory, case1):
     assert n_checked == 40
     for p, _ in pyr_cache.values():
         p.free()
+
+
+def test_batched_stream_config5_geometry(oracle, ctx_factory, case1):
+    """BASELINE config 5 geometry (1920 x 1080 cropped to 1920 x 1072, a stream of frames): a batch of 8 frames with the
+    object at different places must give, frame by frame, the single-frame entry point's list (all 8) and the oracle's (2)."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    ts = case1["templates"].subset(range(0, 361, 3))
+    rows, cols = 1072, 1920
+    img = case1["test"]
+    offs = [(100, 200), (500, 1200), (300, 40), (590, 1310), (0, 0), (250, 700), (400, 1000), (64, 1280)]
+    frames = [synth.embed(img, rows, cols, r, c) for (r, c) in offs]
+    B = len(frames)
+    cap, rec = 512, MATCH_DTYPE.itemsize
+    ctx = ctx_factory()
+    ctx.upload_templates(ts)
+    stream = torch.cuda.Stream(device=dev)
+    d_imgs = torch.from_numpy(np.stack(frames)).to(dev)
+    d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(2 * B, dtype=torch.int32, device=dev)
+    fs = rows * cols * 3
+    ctx.match_batch_device(d_imgs.data_ptr(), fs, B, rows, cols, cols * 3, 3, 90.0, d_out.data_ptr(), cap, d_cnt.data_ptr(),
+                           stream=stream.cuda_stream)
+    stream.synchronize()
+    cnt = d_cnt.cpu().numpy().reshape(B, 2).copy()
+    out = d_out.cpu().numpy().reshape(B, cap * rec).copy()
+    one_out = torch.zeros(cap * rec, dtype=torch.uint8, device=dev)
+    one_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    total = 0
+    for b in range(B):
+        ctx.match_device(d_imgs.data_ptr() + b * fs, rows, cols, cols * 3, 3, 90.0, one_out.data_ptr(), cap, one_cnt.data_ptr(),
+                         stream=stream.cuda_stream)
+        stream.synchronize()
+        n = int(one_cnt.cpu().numpy()[0])
+        assert cnt[b, 1] == 0 and cnt[b, 0] == n
+        assert key(out[b].view(MATCH_DTYPE)[:n]) == key(one_out.cpu().numpy().view(MATCH_DTYPE)[:n]), b
+        total += n
+    assert total > 0
+    for b in (1, 4):
+        pyr = oracle.Pyramid.build(frames[b], [4, 8], 30.0)
+        want = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 90.0)
+        assert key(out[b].view(MATCH_DTYPE)[: cnt[b, 0]]) == key(want), b
+        pyr.free()

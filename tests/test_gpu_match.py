@@ -235,3 +235,34 @@ def test_no_templates_and_empty_selection(ctx_factory, case1):
     ctx.upload_templates(ts)
     ctx.select_range(0, 0)  # an empty shard is legal: no matches
     assert len(ctx.match(frame, 90.0)) == 0
+
+
+def test_full_size_gradient_stage_crop_consistency(oracle, ctx_factory):
+    """BASELINE config 4 frame size (4096 x 4096): the gradient stage is local (halo 5 pixels at level 0; 2 * 5 + 2 at
+    level 1 through pyrDown), so the orientation maps of the full frame must equal, window by window, the oracle's maps of
+    a crop with enough margin — checked on windows that straddle tile seams, sit in the frame corners and in flat areas."""
+    rows = cols = 4096
+    img = synth.scene_gray(404, rows, cols, n_shapes=150)
+    ctx = ctx_factory(T=(4, 8))
+    ctx.build_pyramid(img)
+    q0, q1 = ctx.get_quantized(0), ctx.get_quantized(1)
+    assert q0.shape == (rows, cols) and q1.shape == (rows // 2, cols // 2)
+    rs = np.random.RandomState(9)
+    M = 32  # margin (even, > 12): the crop's own border effects stay inside it
+    wins = [(0, 0), (rows - 320, cols - 320), (0, cols - 320), (1000, 2040), (2040, 1000)] + [
+        (int(rs.randint(0, (rows - 320) // 2)) * 2, int(rs.randint(0, (cols - 320) // 2)) * 2) for _ in range(5)]
+    nonzero = 0
+    for (r0, c0) in wins:
+        crop = np.ascontiguousarray(img[r0:r0 + 320, c0:c0 + 320])
+        pyr = oracle.Pyramid.build(crop, [4, 8], 30.0)
+        o0, o1 = pyr.quantized(0), pyr.quantized(1)
+        # interior of the crop; at a frame border the crop shares the border, so no margin is needed on that side
+        a0 = 0 if r0 == 0 else M
+        b0 = 320 if r0 + 320 == rows else 320 - M
+        a1 = 0 if c0 == 0 else M
+        b1 = 320 if c0 + 320 == cols else 320 - M
+        assert np.array_equal(q0[r0 + a0:r0 + b0, c0 + a1:c0 + b1], o0[a0:b0, a1:b1]), (r0, c0)
+        assert np.array_equal(q1[(r0 + a0) // 2:(r0 + b0) // 2, (c0 + a1) // 2:(c0 + b1) // 2], o1[a0 // 2:b0 // 2, a1 // 2:b1 // 2]), (r0, c0)
+        nonzero += int(np.count_nonzero(o0[a0:b0, a1:b1]))
+        pyr.free()
+    assert nonzero > 1000
