@@ -318,7 +318,9 @@ def main():
             launches = len(v) // prof_steps
             a = np.asarray(v).reshape(prof_steps, launches)
             kern[name] = {"ms_per_step": float(a.sum(axis=1).mean()), "launches": launches,
-                          "avg_launch_us": float(a.mean() * 1e3)}
+                          "avg_launch_us": float(a.mean() * 1e3),
+                          # the launches of a step in order (k_quantize: pyramid level 0, level 1, ...)
+                          "launch_us": [float(x) for x in a.mean(axis=0) * 1e3]}
             if name in alg:
                 kern[name]["algorithmic_bytes_per_step"] = float(sum(alg[name]))
                 kern[name]["achieved_GBps"] = float(sum(alg[name])) / (kern[name]["ms_per_step"] * 1e-3) / 1e9

@@ -118,6 +118,15 @@ int sbm_match_batch_device(sbm_ctx* ctx, const void* d_imgs, int64_t frame_strid
  * the fork, against 70 us). */
 int sbm_set_graph_mode(sbm_ctx* ctx, int32_t enabled);
 
+/* Which gradient kernel (quantizedOrientations + hysteresisGradient, line2Dup.cpp:313-404, :218-311) the match
+ * entry points launch.  mode 0 (default): by launch size — the row-streaming kernel (one wave per 256-column
+ * strip, registers + DPP only, no LDS / barriers) when a launch has thousands of waves of work (a batch of
+ * frames), else the 16 x 64 tile kernel, which also serves the float outputs and widths that are not a multiple
+ * of 4.  mode 1: always the tile kernel.  mode 2: the streaming kernel whenever the geometry allows it.
+ * rows_per_wave > 0 overrides the streaming kernel's rows per work item (rounded up to even).  Results are
+ * bit-identical either way; this is a tuning / test knob. */
+int sbm_set_quantize_mode(sbm_ctx* ctx, int32_t mode, int32_t rows_per_wave);
+
 /* Optional second destination for the results of sbm_match_device /
  * sbm_match_templates: every match record (up to the call's cap) and the final
  * {n_matches, overflow} pair are ALSO stored, with plain stores from the last

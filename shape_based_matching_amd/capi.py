@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "sbm_level_dims", "sbm_match_templates", "sbm_quantized_orientations", "sbm_pyrdown", "sbm_spread",
     "sbm_compute_response_maps", "sbm_linearize", "sbm_similarity", "sbm_similarity_local",
     "sbm_set_profiling", "sbm_get_timings", "sbm_coarse_bytes", "sbm_get_stats",
-    "sbm_set_result_mirror", "sbm_set_graph_mode",
+    "sbm_set_result_mirror", "sbm_set_graph_mode", "sbm_set_quantize_mode",
     "sbm_match_templates_device", "sbm_orientation_bins",
     "sbm_comm_unique_id", "sbm_comm_init", "sbm_comm_destroy", "sbm_match_device_sharded", "sbm_match_batch_device_sharded",
 ]
@@ -96,6 +96,7 @@ def lib() -> C.CDLL:
     L.sbm_get_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.sbm_set_result_mirror.argtypes = [vp, vp, vp]
     L.sbm_set_graph_mode.argtypes = [vp, i32]
+    L.sbm_set_quantize_mode.argtypes = [vp, i32, i32]
     L.sbm_match_templates_device.argtypes = [vp, f32, vp, i64, vp, vp]
     L.sbm_comm_unique_id.argtypes = [vp]
     L.sbm_comm_init.argtypes = [vp, i32, i32, vp]
@@ -241,6 +242,10 @@ class Context:
                                                     C.c_void_p(d_local), cap, C.c_void_p(d_gathered),
                                                     C.c_void_p(gathered_mirror) if gathered_mirror else None,
                                                     C.c_void_p(stream) if stream else None))
+
+    def set_quantize_mode(self, mode: str = "auto", rows_per_wave: int = 0):
+        """gradient kernel choice: "auto" (by launch size), "tile" or "stream"; bit-identical results"""
+        _check(lib().sbm_set_quantize_mode(self._h, {"auto": 0, "tile": 1, "stream": 2}[mode], rows_per_wave))
 
     def set_graph_mode(self, on: bool):
         _check(lib().sbm_set_graph_mode(self._h, 1 if on else 0))

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +17,7 @@
 
 #include "../../include/sbm.h"
 #include "sbm_kernels.h"
+#include "sbm_quantize_stream.h"
 
 using namespace sbm;
 
@@ -145,6 +147,7 @@ struct sbm_ctx {
     };
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
+    int quantize_mode = 0, quantize_hs = 0; // sbm_set_quantize_mode
     bool graph_mode = false; // measured on ROCm 7.2 / MI355X: graph replay is slower than stream launches
     hipStream_t side = nullptr;
     hipEvent_t ev_fork[SBM_MAX_LEVELS] = {};
@@ -305,6 +308,9 @@ int ensure_level(sbm_ctx* c, int l, int rows, int cols)
     c->d_lmc[l].release();
     c->lm_full[l] = c->lm_compact[l] = false;
     c->foff_dirty = true;
+    // This level now holds ONE frame of a geometry the other per-level buffers (next level's image, mask, compact
+    // plane, the batch's frames) were not sized for: the next ensure_geometry() must not take its `same` fast path.
+    c->channels = 0;
     return 0;
 }
 
@@ -327,6 +333,36 @@ int upload_geo(sbm_ctx* c, hipStream_t s)
     return 0;
 }
 
+// Which gradient kernel a launch gets.  The row-streaming kernel (sbm_quantize_stream.h) is the throughput form: a wave
+// walks a 256-column strip for tens of rows, so a launch needs thousands of waves to fill the chip and a single small
+// frame would be a few long serial chains; the tile kernel (k_quantize) is the latency form (1024 short-lived tiles
+// per Mpixel) and the only one with the float outputs and arbitrary widths.  SBM_QUANTIZE=tile|stream forces one for
+// A/B runs, SBM_QS_HS sets the rows per wave.
+int quantize_stream_rows(const sbm_ctx* c, int rows, int cols, int ch, int frames, bool wf)
+{
+    static const char* env = getenv("SBM_QUANTIZE");
+    static const int env_hs = getenv("SBM_QS_HS") ? atoi(getenv("SBM_QS_HS")) : 0;
+    const int mode = c->quantize_mode ? c->quantize_mode : (env && !strcmp(env, "tile") ? 1 : (env && !strcmp(env, "stream") ? 2 : 0));
+    const int force_hs = c->quantize_hs ? c->quantize_hs : env_hs;
+    if (wf || mode == 1 || cols < 4 || (cols & 3) || (int64_t)rows * cols >= (int64_t)0x7ff00000) return 0;
+    const int64_t strips = (cols + QS_USEFUL - 1) / QS_USEFUL;
+    if (force_hs > 0) return (force_hs + 1) & ~1;
+    // The kernel is bound by vector-instruction issue, and a SIMD needs its full set of resident waves (3 at the
+    // BGR kernel's register count, 6 for gray) to hide the scalar bookkeeping and dependency bubbles of each: a launch
+    // takes about  ceil(waves / resident slots) x (hs + 10 halo rows).  Choose the rows per wave that minimise it.
+    const int64_t slots = 1024 * (ch == 3 ? 3 : 6);
+    int hs = 0;
+    int64_t best = INT64_MAX;
+    for (int h = 8; h <= 128; h += 2) {
+        const int64_t waves = strips * ((rows + h - 1) / h) * frames;
+        const int64_t cost = ((waves + slots - 1) / slots) * (std::min(h, rows) + 10);
+        if (cost <= best) best = cost, hs = h;
+    }
+    // small launches: the 16 x 64 tiles of k_quantize finish sooner than a few long serial chains
+    if (mode != 2 && (int64_t)rows * cols * frames < ((int64_t)8 << 20)) return 0;
+    return hs;
+}
+
 int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, int cols, int stride, int ch,
                     const uint8_t* d_mask, float weak, uint8_t* d_out, float* d_mag, float* d_ori, uint8_t* d_pyr,
                     int frames = 1, int64_t img_fs = 0)
@@ -335,6 +371,29 @@ int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, i
     const float thr_sq = weak * weak;
     const bool wf = d_mag || d_ori;
     const int64_t out_fs = (int64_t)rows * cols, pyr_fs = (int64_t)(rows / 2) * (cols / 2) * ch; // the context's own per-frame buffers
+    if (const int hs = quantize_stream_rows(c, rows, cols, ch, frames, wf)) {
+        QSArgs a;
+        memset(&a, 0, sizeof a);
+        a.img = d_img;
+        a.mask = d_mask;
+        a.out = d_out;
+        a.pyr = d_pyr;
+        a.img_fs = img_fs;
+        a.out_fs = out_fs;
+        a.pyr_fs = pyr_fs;
+        a.rows = rows;
+        a.cols = cols;
+        a.stride = stride;
+        a.thr_i = thr_sq < 2147483000.f ? (int)floorf(thr_sq) : INT_MAX; // mag is an integer: mag > weak^2 <=> mag > floor(weak^2)
+        a.hs = hs;
+        a.n_strips = (cols + QS_USEFUL - 1) / QS_USEFUL;
+        a.n_rblocks = (rows + hs - 1) / hs;
+        const dim3 g((unsigned)((a.n_strips * a.n_rblocks + 3) / 4), (unsigned)frames);
+        if (ch == 1) SBM_LAUNCH(c, "k_quantize", (k_quantize_stream<1>), g, dim3(256), 0, s, a);
+        else SBM_LAUNCH(c, "k_quantize", (k_quantize_stream<3>), g, dim3(256), 0, s, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     // many tiles per CU (a batch of frames): 512-thread blocks, four of them per CU; else 1024-thread blocks (tile latency)
     const bool many = (int64_t)grid.x * grid.y * grid.z >= 2048;
 #define SBM_QUANTIZE(CH_, WF_)                                                                                              \
@@ -469,6 +528,9 @@ int ensure_foff(sbm_ctx* c, hipStream_t s)
                        c->d_flabel.as<uint8_t>(), c->d_flevel.as<uint8_t>(), c->n_features, g,
                        g + SBM_MAX_LEVELS, g + 2 * SBM_MAX_LEVELS, st, c->d_foff.as<int32_t>());
     HIP_TRY(hipGetLastError());
+    // The similarity kernels may be enqueued on a different stream than `s` (graph replay, a caller's stream):
+    // the table must be complete before any of them can start.  Only runs after a template / geometry change.
+    HIP_TRY(hipStreamSynchronize(s));
     c->foff_dirty = false;
     return 0;
 }
@@ -920,7 +982,7 @@ int sbm_match_device(sbm_ctx* c, const void* d_img, int32_t rows, int32_t cols, 
     if (!c->graph_mode || c->profiling) {
         if (int e = ensure_geometry(c, rows, cols, channels)) return e;
         if (c->profiling && !c->profiling_keep) c->clear_timings();
-        if (int e = prepare_templates(c, c->stream, threshold, cap)) return e;
+        if (int e = prepare_templates(c, s, threshold, cap)) return e;
         if (int e = enqueue_pyramid(c, s, (const uint8_t*)d_img, stride, (const uint8_t*)d_mask, (int32_t*)d_count)) return e;
         if (int e = enqueue_coarse(c, s, (sbm_match_rec*)d_out, cap, (int32_t*)d_count)) return e;
         return enqueue_local(c, s, (sbm_match_rec*)d_out, cap, (int32_t*)d_count);
@@ -985,7 +1047,7 @@ int sbm_match_batch_device(sbm_ctx* c, const void* d_imgs, int64_t frame_stride,
     if (dirty) HIP_TRY(hipDeviceSynchronize());
     if (int e = ensure_geometry(c, rows, cols, channels, n_frames)) return e;
     if (c->profiling && !c->profiling_keep) c->clear_timings();
-    if (int e = prepare_templates(c, c->stream, threshold, cap)) return e;
+    if (int e = prepare_templates(c, s, threshold, cap)) return e;
     if (int e = enqueue_pyramid(c, s, (const uint8_t*)d_imgs, stride, (const uint8_t*)d_mask, (int32_t*)d_counts, n_frames, frame_stride)) return e;
     if (int e = enqueue_coarse(c, s, (sbm_match_rec*)d_out, cap, (int32_t*)d_counts, n_frames)) return e;
     return enqueue_local(c, s, (sbm_match_rec*)d_out, cap, (int32_t*)d_counts, n_frames);
@@ -999,6 +1061,15 @@ int sbm_match_templates_device(sbm_ctx* c, float threshold, void* d_out, int64_t
     if (!c->have_thr || memcmp(&threshold, &c->thr_cached, 4) != 0 || c->foff_dirty) HIP_TRY(hipDeviceSynchronize());
     if (c->profiling && !c->profiling_keep) c->clear_timings();
     return enqueue_templates(c, s, threshold, (sbm_match_rec*)d_out, cap, (int32_t*)d_count);
+}
+
+int sbm_set_quantize_mode(sbm_ctx* c, int32_t mode, int32_t rows_per_wave)
+{
+    if (!c || mode < 0 || mode > 2 || rows_per_wave < 0 || rows_per_wave > 4096) return fail(SBM_ERR_INVALID, "bad quantize mode");
+    c->quantize_mode = mode;
+    c->quantize_hs = rows_per_wave;
+    c->drop_graphs(); // captured launches hold the old kernel choice
+    return 0;
 }
 
 int sbm_set_graph_mode(sbm_ctx* c, int32_t enabled)
