@@ -118,6 +118,7 @@ struct sbm_ctx {
     // of such a level is materialised on demand for the stage entry points (ensure_full_lm).
     DevBuf d_lmc[SBM_MAX_LEVELS];
     bool lm_full[SBM_MAX_LEVELS]{}, lm_compact[SBM_MAX_LEVELS]{}; // which form of level l is current (frame 0 .. batch)
+    bool lm_strip[SBM_MAX_LEVELS]{}; // the compact plane of level l is strip-interleaved (lm_strip_offset)
     DevBuf d_geo; // T[L], W[L], H[L] as int32 then stride[L] as int64
     bool foff_dirty = true;
     bool counters_fresh = false; // the linear-memory launch of this frame already reset the counters
@@ -279,7 +280,7 @@ int ensure_geometry(sbm_ctx* c, int rows, int cols, int channels, int frames = 1
         c->d_lmc[l].release();
         if (l < c->L - 1)
             if (int e = c->d_lmc[l].ensure(B * c->lm_stride[l], true)) return e;
-        c->lm_full[l] = c->lm_compact[l] = false;
+        c->lm_full[l] = c->lm_compact[l] = c->lm_strip[l] = false;
     }
     if (B > (size_t)c->batch) { // per-frame candidate lists and counters
         if (int e = c->d_cands.ensure(B * c->cand_cap * sizeof(Cand))) return e;
@@ -359,7 +360,7 @@ int quantize_stream_rows(const sbm_ctx* c, int rows, int cols, int ch, int frame
         if (cost <= best) best = cost, hs = h;
     }
     // small launches: the 16 x 64 tiles of k_quantize finish sooner than a few long serial chains
-    if (mode != 2 && (int64_t)rows * cols * frames < ((int64_t)8 << 20)) return 0;
+    if (mode != 2 && (int64_t)rows * cols * frames < ((int64_t)4 << 20)) return 0;
     return hs;
 }
 
@@ -433,7 +434,7 @@ int ensure_full_lm(sbm_ctx* c, int l, hipStream_t s)
     const int T = c->cfg.T[l];
     const int64_t n = (int64_t)T * T * (c->cols[l] / T) * (c->rows[l] / T);
     hipLaunchKernelGGL(k_expand_lm, dim3((unsigned)std::min<int64_t>((n / 4 + 255) / 256, 4096)), dim3(256), 0, s, c->d_lmc[l].as<uint8_t>(), n,
-                       c->d_lm[l].as<uint8_t>(), c->lm_stride[l]);
+                       c->d_lm[l].as<uint8_t>(), c->lm_stride[l], c->lm_strip[l] ? 1 : 0, c->cols[l] / T, c->rows[l] / T);
     HIP_TRY(hipGetLastError());
     c->lm_full[l] = true;
     return 0;
@@ -584,12 +585,17 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
         for (int l = 0; l < c->L; ++l) {
             const int T = c->cfg.T[l], W = c->cols[l] / T, H = c->rows[l] / T;
             const bool compact = l < c->L - 1 && c->d_lmc[l].p && use_compact_lm();
+            // the refinement pass reads 16 x 16 cells per feature: strip-interleave the plane so that they are 2 - 4 lines
+            static const bool strip_ok = !(getenv("SBM_STRIP_LM") && atoi(getenv("SBM_STRIP_LM")) == 0); // A/B knob
+            const bool strip = compact && strip_ok && (W & 15) == 0;
             a.lv[l] = LmLevelArgs{c->d_quant[l].as<uint8_t>(), compact ? c->d_lmc[l].as<uint8_t>() : c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
                                   c->rows[l], c->cols[l], W, H, T, blocks, (int64_t)c->rows[l] * c->cols[l],
-                                  (int64_t)(compact ? 1 : 8) * c->lm_stride[l], compact ? 1 : 0};
+                                  (int64_t)(compact ? 1 : 8) * c->lm_stride[l], strip ? 2 : (compact ? 1 : 0)};
             c->lm_compact[l] = compact;
+            c->lm_strip[l] = strip;
             c->lm_full[l] = !compact;
-            blocks += (int)(((int64_t)c->rows[l] * (W >> 2) + 255) / 256);
+            const int64_t items = strip ? (int64_t)(W >> 4) * ((H + 15) >> 4) * T * 64 : (int64_t)c->rows[l] * (W >> 2);
+            blocks += (int)((items + 255) / 256);
         }
         if (reset_count) {
             a.counters = c->d_counters.as<int32_t>();
@@ -679,8 +685,9 @@ int enqueue_local(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap, 
                    c->d_foff.as<int32_t>(), c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),          \
                    c->d_cands.as<Cand>(), counters, (int)c->cand_cap, l == 0 ? 1 : 0, d_out, d_count, (int)cap, c->mirror_out,     \
                    c->mirror_count, c->profiling ? 1 : 0, (int64_t)(FS_) * c->lm_stride[l], c->d_flabel.as<uint8_t>())
-        if (compact) { SBM_LOCAL(true, c->d_lmc[l].as<uint8_t>(), 1); }
-        else { SBM_LOCAL(false, c->d_lm[l].as<uint8_t>(), 8); }
+        if (compact && c->lm_strip[l]) { SBM_LOCAL(2, c->d_lmc[l].as<uint8_t>(), 1); }
+        else if (compact) { SBM_LOCAL(1, c->d_lmc[l].as<uint8_t>(), 1); }
+        else { SBM_LOCAL(0, c->d_lm[l].as<uint8_t>(), 8); }
 #undef SBM_LOCAL
 #undef SBM_LOCAL_LW
         HIP_TRY(hipGetLastError());

@@ -816,6 +816,16 @@ __global__ __launch_bounds__(256) void k_build_lm(const uint8_t* __restrict__ q,
     }
 }
 
+// Strip-interleaved compact plane of a refinement-only level (needs W % 16 == 0): inside sub-plane
+// sub = (y%T)*T + x%T the W x H grid is cut into W/16 column strips of 16 cells, and a strip is stored row after
+// row, 16 bytes per row:  offset = sub*W*H + ((gx / 16) * H + gy) * 16 + gx % 16.
+// similarityLocal (line2Dup.cpp:860-922) reads 16 x 16 cells per feature; row-major that is 16 pieces of 16 bytes in
+// 16 different 128-byte lines, here it is two runs of 256 contiguous bytes at most (one when gx % 16 == 0).
+__host__ __device__ __forceinline__ int64_t lm_strip_offset(int sub, int gy, int gx, int W, int H)
+{
+    return (int64_t)sub * W * H + ((int64_t)(gx >> 4) * H + gy) * 16 + (gx & 15);
+}
+
 // ---- register-only variant for T = 4 and T = 8 (the reference's strides) ----
 // One lane owns 4 consecutive grid cells (4*T pixels) of one (ty, gy) pixel row
 // r0 = gy*T + ty: it ORs the T source rows r0..r0+T-1 (16-byte loads), ORs T
@@ -832,14 +842,30 @@ __device__ __forceinline__ uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t 
 template <int T>
 __device__ __forceinline__ void build_lm_rows_item(const uint8_t* __restrict__ q, int rows, int cols, int W, int H,
                                                    uint8_t* __restrict__ lm, int64_t lm_stride, int64_t item,
-                                                   bool compact)
+                                                   int compact)
 {
     constexpr int NQ = T / 4 * 4; // dwords of own pixels per lane (4 cells * T px / 4)
-    const int lanes_per_row = W >> 2;
-    const int64_t row_id = item / lanes_per_row; // = gy * T + ty  (a pixel row index)
-    const int k = (int)(item - row_id * lanes_per_row);
-    if (row_id >= rows) return;
-    const int r0 = (int)row_id;
+    int r0, k;
+    if (compact == 2) {
+        // strip-interleaved plane: a wave = one strip (4 lanes x 4 cells) x 16 consecutive grid rows of one ty, so that
+        // each of its stores is one contiguous run of 256 bytes (16 strip rows of 16 bytes)
+        const int n_s = W >> 4, gyb_n = (H + 15) >> 4;
+        const int lane_in = (int)(item & 63);
+        const int64_t grp = item >> 6;
+        const int S = (int)(grp % n_s);
+        const int64_t rest = grp / n_s;
+        const int gyb = (int)(rest % gyb_n), ty_ = (int)(rest / gyb_n);
+        const int gy_ = gyb * 16 + (lane_in >> 2);
+        if (ty_ >= T || gy_ >= H) return;
+        r0 = gy_ * T + ty_;
+        k = S * 4 + (lane_in & 3);
+    } else {
+        const int lanes_per_row = W >> 2;
+        const int64_t row_id = item / lanes_per_row; // = gy * T + ty  (a pixel row index)
+        k = (int)(item - row_id * lanes_per_row);
+        if (row_id >= rows) return;
+        r0 = (int)row_id;
+    }
     const int gy = r0 / T, ty = r0 - gy * T;
     const int c0 = k * 4 * T; // first pixel column of this lane
     // vertical OR of rows r0 .. r0+T-1 (clipped at the bottom, :626-627), own pixels + T px of right halo
@@ -893,7 +919,9 @@ __device__ __forceinline__ void build_lm_rows_item(const uint8_t* __restrict__ q
         const uint32_t p23 = perm_b32(d3, d2, 0x00000c0cu | ((4 + b) << 24) | (b << 16)); // {0, 0, d2.b, d3.b}
         const uint32_t sp = p01 | p23;
         const int64_t dst = (int64_t)(ty * T + tx) * WH + cell;
-        if (compact) { // one plane of spread bytes: the reader applies the response LUT for its own orientation
+        if (compact == 2) { // strip-interleaved spread plane (lm_strip_offset): a 16 x 16 patch is 2 - 4 cache lines
+            *(uint32_t*)(lm + lm_strip_offset(ty * T + tx, gy, k * 4, W, H)) = sp;
+        } else if (compact) { // one plane of spread bytes: the reader applies the response LUT for its own orientation
             *(uint32_t*)(lm + dst) = sp;
         } else {
 #pragma unroll
@@ -912,7 +940,7 @@ struct LmLevelArgs {
     int32_t block_begin; // first block of this level
     int64_t q_fs, lm_fs; // bytes from one frame of a batch to the next
     int32_t compact;     // 1: lm is ONE plane [T*T][W*H] of spread bytes (a level that only the refinement pass
-                         // reads): 1/8 of the stores and of the HBM write-back
+                         // reads): 1/8 of the stores and of the HBM write-back; 2: the same plane strip-interleaved
 };
 struct LmArgs {
     LmLevelArgs lv[SBM_MAX_LEVELS];
@@ -936,18 +964,23 @@ __global__ __launch_bounds__(256) void k_build_lm_rows(const LmArgs a)
     const int64_t item = (int64_t)((int)blockIdx.x - p.block_begin) * 256 + threadIdx.x;
     const uint8_t* q = p.q + frame * p.q_fs;
     uint8_t* lm = p.lm + frame * p.lm_fs;
-    if (p.T == 4) build_lm_rows_item<4>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact != 0);
-    else build_lm_rows_item<8>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact != 0);
+    if (p.T == 4) build_lm_rows_item<4>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact);
+    else build_lm_rows_item<8>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact);
 }
 
 // compact plane (spread bytes) -> the 8 response planes, for the stage entry points that hand out or read a
 // full linear memory of a refinement-only level
 __global__ __launch_bounds__(256) void k_expand_lm(const uint8_t* __restrict__ lmc, int64_t n_bytes,
-                                                   uint8_t* __restrict__ lm, int64_t lm_stride)
+                                                   uint8_t* __restrict__ lm, int64_t lm_stride, int strip, int W, int H)
 {
     const int64_t n4 = n_bytes >> 2; // T*T*W*H is a multiple of 16
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const uint32_t v = ((const uint32_t*)lmc)[i];
+        int64_t src = 4 * i;
+        if (strip) { // i enumerates the row-major output: [sub][gy][gx .. gx+3]
+            const int64_t wh = (int64_t)W * H, sub = (4 * i) / wh, rem = 4 * i - sub * wh;
+            src = lm_strip_offset((int)sub, (int)(rem / W), (int)(rem % W), W, H);
+        }
+        const uint32_t v = *(const uint32_t*)(lmc + src);
 #pragma unroll
         for (int o = 0; o < 8; ++o) *(uint32_t*)(lm + o * lm_stride + 4 * i) = response4(v, o);
     }
@@ -1103,6 +1136,75 @@ __device__ __forceinline__ void accumulate_features(const uint8_t* __restrict__ 
     hi += (acc >> 8) & 0x00ff00ffu;
 }
 
+// The refinement patch of one candidate from a STRIP-interleaved compact plane (lm_strip_offset): lane = (row r =
+// lane >> 2, column quarter lq = lane & 3) of the 16 x 16 patch.  Patch columns start at grid column gx0 (any
+// alignment): with q = (gx0 & 15) >> 2 and sh = gx0 & 3 the lane needs the two aligned dwords a = q + lq and a + 1
+// of the 32-byte run [strip S0 row | strip S0+1 row] and funnel-shifts them by sh bytes (v_alignbyte, wave-uniform
+// shift).  Per feature the wave touches 2 - 4 cache lines instead of 16.  Same calling convention as
+// accumulate_features (all 64 lanes active; out-of-image features read the plane's zero tail).
+template <int LOG2T>
+__device__ __forceinline__ void accumulate_features_strip(const uint8_t* __restrict__ lmc, const uint32_t* __restrict__ fxy,
+                                                          const uint8_t* __restrict__ flabel, int f0, int count, int rows,
+                                                          int cols, int ox, int oy, int W, int H, uint32_t& lo, uint32_t& hi)
+{
+    constexpr int T = 1 << LOG2T;
+    const int lane = threadIdx.x & 63;
+    const uint32_t lq = (uint32_t)lane & 3u;
+    const uint32_t p0 = (uint32_t)(lane >> 2) * 16u + lq * 4u; // byte offset of (row r, dword lq) inside a strip
+    const uint32_t wrap = (uint32_t)H * 16u - 16u;             // from the end of a strip row to the same row of the next strip
+    const uint32_t zero16 = (uint32_t)(((int64_t)T * T * W * H) >> 4); // the plane's zero tail (>= H*16 + 272 bytes, lm_stride_for)
+    uint32_t acc = 0;
+    lo = hi = 0;
+    int pending = 0;
+    count = __builtin_amdgcn_readfirstlane(count);
+    f0 = __builtin_amdgcn_readfirstlane(f0);
+    for (int b = 0; b < count; b += 64) {
+        // one record per feature: (byte offset of its strip row) / 16 in the high bits, q | sh << 2 | label << 4 below
+        uint32_t rec = zero16 << 7;
+        if (b + lane < count) {
+            const uint32_t xy = fxy[f0 + b + lane];
+            const int x = (int)(xy & 0xffff) + ox, y = (int)(xy >> 16) + oy;
+            const int gx0 = x >> LOG2T, gy0 = y >> LOG2T;
+            uint32_t base16 = zero16;
+            if (x >= 0 && y >= 0 && x < cols && y < rows)
+                base16 = (uint32_t)(lm_strip_offset(((y & (T - 1)) << LOG2T) | (x & (T - 1)), gy0, gx0 & ~15, W, H) >> 4);
+            rec = (base16 << 7) | (uint32_t)(((gx0 & 15) >> 2) | ((gx0 & 3) << 2)) | ((uint32_t)flabel[f0 + b + lane] << 4);
+        }
+        const int nb = count - b < 64 ? count - b : 64;
+        auto batch = [&](auto N, int u) {
+            constexpr int n = decltype(N)::value;
+            uint32_t d0[n], d1[n];
+            uint32_t pr[n];
+#pragma unroll
+            for (int k = 0; k < n; ++k) {
+                pr[k] = (uint32_t)__builtin_amdgcn_readlane((int)rec, (u + k) & 63);
+                const uint8_t* p = lmc + ((size_t)(pr[k] >> 7) << 4) + ((pr[k] & 3u) << 2); // + q dwords
+                const uint32_t t = (pr[k] & 3u) + lq;                                      // dword index a = q + lq in 0 .. 6
+                d0[k] = *(const uint32_t*)(p + (p0 + (t >> 2) * wrap));
+                d1[k] = *(const uint32_t*)(p + (p0 + ((t + 1) >> 2) * wrap) + 4);
+            }
+#pragma unroll
+            for (int k = 0; k < n; ++k)
+                acc += response4(__builtin_amdgcn_alignbyte(d1[k], d0[k], (pr[k] >> 2) & 3u), (int)((pr[k] >> 4) & 7u));
+            pending += n;
+            if (pending + FBL > 63) {
+                lo += acc & 0x00ff00ffu;
+                hi += (acc >> 8) & 0x00ff00ffu;
+                acc = 0;
+                pending = 0;
+            }
+        };
+        int u = 0;
+        for (; u + FBL <= nb; u += FBL) batch(std::integral_constant<int, FBL>{}, u);
+        if (FBL > 8 && nb - u >= 8) { batch(std::integral_constant<int, 8>{}, u); u += 8; }
+        if (nb - u >= 4) { batch(std::integral_constant<int, 4>{}, u); u += 4; }
+        if (nb - u >= 2) { batch(std::integral_constant<int, 2>{}, u); u += 2; }
+        if (nb - u >= 1) batch(std::integral_constant<int, 1>{}, u);
+    }
+    lo += acc & 0x00ff00ffu;
+    hi += (acc >> 8) & 0x00ff00ffu;
+}
+
 __device__ __forceinline__ int unpack4(uint32_t lo, uint32_t hi, int k)
 {
     return (k & 1) ? (int)((hi >> (8 * (k - 1))) & 0xffff) : (int)((lo >> (8 * k)) & 0xffff);
@@ -1224,18 +1326,30 @@ __global__ __launch_bounds__(256) void k_similarity_coarse(
     const int32_t* __restrict__ class_idx, const int32_t* __restrict__ template_id, Cand* __restrict__ cands,
     int32_t* __restrict__ counters, int cap, int64_t lm_fs)
 {
-    // batch of frames: frame = blockIdx.z; per-frame linear memories, candidate list and counters
-    lm += (size_t)blockIdx.z * lm_fs;
-    cands += (size_t)blockIdx.z * cap;
-    counters += (size_t)blockIdx.z * 40;
+    // batch of frames: per-frame linear memories, candidate list and counters
     __shared__ uint32_t s_red[4][8][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int chunk_id = blockIdx.x, templ_slot = blockIdx.y, frame = blockIdx.z;
+    const bool frame_affinity = (gridDim.z & 7) == 0;
+    if (frame_affinity) {
+        // Workgroups are dealt to the 8 XCDs round-robin by linear id and each XCD has its own 4 MiB L2.  With a batch
+        // of 8k frames give XCD x the frames x, x+8, ... one after the other: its L2 then holds ONE frame's linear
+        // memories at a time (2 MiB on the bench configuration) instead of every frame's.  Pure speed.
+        const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const uint32_t xcd = lin & 7, j = lin >> 3, per = gridDim.x * gridDim.y;
+        const uint32_t fl = j / per, rem = j - fl * per;
+        frame = (int)(xcd + 8 * fl);
+        templ_slot = (int)(rem / gridDim.x);
+        chunk_id = (int)(rem - (uint32_t)templ_slot * gridDim.x);
+    }
+    lm += (size_t)frame * lm_fs;
+    cands += (size_t)frame * cap;
+    counters += (size_t)frame * 40;
     // XCD-aware (chunk, template) assignment.  Workgroups are dealt to the 8 XCDs round-robin by linear id,
     // and each XCD has its own 4 MiB L2: give XCD x the position chunks [x*cpx, (x+1)*cpx) of EVERY
     // template, so that one L2 only ever sees the slice of the linear memories those chunks read
     // (chunk span + template extent) instead of all of them.  Pure speed: any mapping is correct.
-    int chunk_id = blockIdx.x, templ_slot = blockIdx.y;
-    if ((gridDim.x & 7) == 0) {
+    if (!frame_affinity && (gridDim.x & 7) == 0) {
         const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
         const int cpx = (int)gridDim.x >> 3;
         const int xcd = lin & 7, slot = lin >> 3;
@@ -1359,7 +1473,7 @@ __device__ __forceinline__ void publish_counts(int32_t* __restrict__ counters, i
 // LOCAL_WAVES waves each take a contiguous slice of the features and the partial
 // sums meet in LDS.  Result (packed u16) valid in wave 0.
 constexpr int LOCAL_WAVES = 16;
-template <bool COMPACT = false, int LW = LOCAL_WAVES>
+template <int COMPACT = 0, int LW = LOCAL_WAVES>
 __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int64_t lm_stride, const DevTL tl,
                                             const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
                                             int rows, int cols, int W, int H, int T, int ox, int oy,
@@ -1374,8 +1488,13 @@ __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int6
     const int f0 = wave * chunk;
     int cnt = tl.nf - f0;
     cnt = cnt < 0 ? 0 : (cnt > chunk ? chunk : cnt);
-    accumulate_features<COMPACT>(lm, fxy + tl.feat_off, foff + tl.feat_off, f0, cnt, rows, cols, ox, oy, delta, zero_addr, 0, lo, hi,
-                                 COMPACT ? flabel + tl.feat_off : nullptr, (int)lm_stride);
+    if (COMPACT == 2) {
+        if (T == 4) accumulate_features_strip<2>(lm, fxy + tl.feat_off, flabel + tl.feat_off, f0, cnt, rows, cols, ox, oy, W, H, lo, hi);
+        else accumulate_features_strip<3>(lm, fxy + tl.feat_off, flabel + tl.feat_off, f0, cnt, rows, cols, ox, oy, W, H, lo, hi);
+    } else {
+        accumulate_features<COMPACT != 0>(lm, fxy + tl.feat_off, foff + tl.feat_off, f0, cnt, rows, cols, ox, oy, delta, zero_addr, 0, lo, hi,
+                                          COMPACT ? flabel + tl.feat_off : nullptr, (int)lm_stride);
+    }
     s_part[wave][0][lane] = lo;
     s_part[wave][1][lane] = hi;
     __syncthreads();
@@ -1394,7 +1513,7 @@ __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int6
 // apply the per-level filter (:1290-1292); at level 0 emit the final Match record.
 // LW waves per candidate: 16 when a launch has few candidates per CU (their latency is the launch's duration), 4 for
 // a batch of frames (4x as many candidates in flight, idle slots 4x cheaper to dispatch).
-template <bool COMPACT, int LW>
+template <int COMPACT, int LW>
 __global__ __launch_bounds__(64 * LW) void k_similarity_local(
     const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int l,
     const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
@@ -1509,7 +1628,7 @@ __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local_patch(con
     __shared__ uint32_t s_part[LOCAL_WAVES][2][64];
     const int ox = (cx / T - 8) * T, oy = (cy / T - 8) * T;
     uint32_t lo, hi;
-    local_patch(lm, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi);
+    local_patch<0, LOCAL_WAVES>(lm, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi);
     if (threadIdx.x < 64) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) dst[threadIdx.x * 4 + k] = (uint16_t)unpack4(lo, hi, k);

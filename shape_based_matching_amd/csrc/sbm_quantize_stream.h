@@ -46,7 +46,7 @@ namespace sbm {
 constexpr int QS_LANE_PX = 4;
 constexpr int QS_HALO_LANES = 2;
 constexpr int QS_USEFUL = (64 - 2 * QS_HALO_LANES) * QS_LANE_PX; // 240 useful columns per strip
-constexpr int QS_PREFETCH = 2;                                   // source rows in flight ahead of the one being consumed
+constexpr int QS_PREFETCH = 4;                                   // source rows in flight ahead of the one being consumed
 
 struct QSArgs {
     const uint8_t* img;  // frame 0, level image, `stride` bytes per row, CH interleaved channels
@@ -164,6 +164,7 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
 
     int flat_cnt = 0;         // consecutive loaded rows of one constant colour (the latest included)
     uint32_t flat_key = 0;    // that colour
+    bool in_run = false;      // the previous row took the constant-row shortcut (the carried state is already constant)
 
     for (int i0 = 0; i0 < n_iter; i0 += 7) {
 #pragma unroll
@@ -178,18 +179,8 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
 #pragma unroll
             for (int q = 0; q < ND; ++q) d[q] = dq[k][q];
 
-            // ---- border replicate, constant-row test, de-interleave + widen ----
-            if (border_strip) {
-                if (CH == 3) {
-                    const V n0 = perm(d[2 % ND], d[0], selA), n2 = perm(d[2 % ND], d[0], selC);
-                    const V n1 = select(outside, perm(d[2 % ND], d[0], selB), d[1 % ND]);
-                    d[0] = n0;
-                    d[1 % ND] = n1;
-                    d[2 % ND] = n2;
-                } else {
-                    d[0] = perm(d[0], d[0], selA);
-                }
-            }
+            // ---- constant-row test on the loaded bytes (a clamped group outside the image is a group of the image, so the
+            //      test sees the replicated border as well) ----
             bool row_flat;
             uint32_t key;
             if (CH == 3) {
@@ -203,20 +194,36 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
             }
             flat_cnt = row_flat ? (flat_cnt > 0 && key == flat_key ? flat_cnt + 1 : 1) : 0;
             flat_key = key;
-            if (CH == 3) {
-                st.win[k][0][0] = perm(d[1 % ND], d[0], 0x0c060c00u);
-                st.win[k][1 % CH][0] = perm(d[1 % ND], d[0], 0x0c070c01u);
-                st.win[k][2 % CH][0] = perm(d[2 % ND], d[0], 0x0c040c02u);
-                st.win[k][0][1] = perm(d[2 % ND], d[0], 0x0c050c03u);
-                st.win[k][1 % CH][1] = perm(d[2 % ND], d[1 % ND], 0x0c060c00u);
-                st.win[k][2 % CH][1] = perm(d[2 % ND], d[1 % ND], 0x0c070c01u);
-            } else {
-                st.win[k][0][0] = perm(d[0], d[0], 0x0c020c00u);
-                st.win[k][0][1] = perm(d[0], d[0], 0x0c030c01u);
+            const bool fast = flat_cnt >= 11; // source rows y-10 .. y are one constant colour
+
+            // ---- border replicate, de-interleave + widen into window slot k.  Skipped inside a constant run: the slot
+            //      holds row y-7, which is the same constant row ----
+            if (!fast) {
+                if (border_strip) {
+                    if (CH == 3) {
+                        const V n0 = perm(d[2 % ND], d[0], selA), n2 = perm(d[2 % ND], d[0], selC);
+                        const V n1 = select(outside, perm(d[2 % ND], d[0], selB), d[1 % ND]);
+                        d[0] = n0;
+                        d[1 % ND] = n1;
+                        d[2 % ND] = n2;
+                    } else {
+                        d[0] = perm(d[0], d[0], selA);
+                    }
+                }
+                if (CH == 3) {
+                    st.win[k][0][0] = perm(d[1 % ND], d[0], 0x0c060c00u);
+                    st.win[k][1 % CH][0] = perm(d[1 % ND], d[0], 0x0c070c01u);
+                    st.win[k][2 % CH][0] = perm(d[2 % ND], d[0], 0x0c040c02u);
+                    st.win[k][0][1] = perm(d[2 % ND], d[0], 0x0c050c03u);
+                    st.win[k][1 % CH][1] = perm(d[2 % ND], d[1 % ND], 0x0c060c00u);
+                    st.win[k][2 % CH][1] = perm(d[2 % ND], d[1 % ND], 0x0c070c01u);
+                } else {
+                    st.win[k][0][0] = perm(d[0], d[0], 0x0c020c00u);
+                    st.win[k][0][1] = perm(d[0], d[0], 0x0c030c01u);
+                }
             }
 
             const int yg = y - 3, ys = y - 4, yv = y - 5; // rows of the Gaussian / Sobel+label / vote stages
-            const bool fast = flat_cnt >= 11;               // source rows y-10 .. y are one constant colour
             const uint32_t out_row = (uint32_t)(yv * cols); // byte offset of output row yv (used when yv >= 0)
 
             // ---- cv::pyrDown row oy (source rows 2oy-2 .. 2oy+2 = window rows y-4 .. y) ----
@@ -275,6 +282,8 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
                 // are the colour c (dx = 0, sx = 4c), the vote words of rows y-4, y-5 are bin 0 (3 per horizontal sum),
                 // nothing is strong in row y-4.
                 if (i >= 10) buf_store_u32(out_buf, out_off, out_row, splat(0u));
+                if (!in_run) { // first row of the run: the following ones leave the state as it is
+                in_run = true;
 #pragma unroll
                 for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -288,7 +297,9 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
                     st.hs1[j] = st.hs2[j] = cold_splat(3u);
                     st.sm1[j] = cold_splat(0u);
                 }
+                }
             } else {
+            in_run = false;
             // ---- Gaussian at row yg + Sobel horizontal parts (needed for smoothed rows R0-2 .. R1+1 inside the image) ----
             V dxc[CH][2], sxc[CH][2];
             const bool do_gauss = i >= 6 && yg >= 0 && yg <= rows - 1;
