@@ -1,22 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the LINE-2D match() hot path on MI355X.
 
-A step = one pass of the hot path over one batch of frames that are already
-resident in HBM: for every frame one whole Detector::match
-(line2Dup.cpp:1078-1150) — gradient quantisation -> pyramid -> spread/response/
-linearize -> similarity over this rank's template shard -> 16x16 refinement ->
-match records — with the per-frame match lists all-gathered over RCCL when
-N > 1 and stored in pinned host memory.  Metric: templates * Mpixels / s
+A step = one pass of the hot path over one batch of frames that are already resident in HBM: for every frame one
+whole Detector::match (line2Dup.cpp:1078-1150) — gradient quantisation -> pyramid -> spread/response/linearize ->
+similarity over this rank's template shard -> 16x16 refinement -> match records — with the per-frame match lists
+all-gathered over RCCL when N > 1 and stored in pinned host memory.  Metric: templates * Mpixels / s
 (BASELINE.json), whole job: templates x Mpixels x frames per step x steps / time.
 
-Workload (BASELINE.json configs[1], "case1 on 1x MI355X"): the reference's
-case1 test image centred on a 1024 x 1024 BGR canvas, 360 case1 rotation
-templates (131 / 71 features) per GPU, pyramid {4, 8}, threshold 90.  With N
-GPUs the template set is N x 360 (weak scaling), sharded by contiguous ranges.
---batch frames per step (default 16: sbm_match_batch_device launches every kernel
-once for the whole batch; frame b is the workload frame shifted 8*b columns) and
---inflight independent slots (contexts + streams, default 2) used round-robin;
---batch 1 --inflight 1 is strictly one frame at a time (sbm_match_device).
+Default workload (BASELINE.json configs[1], "case1 on 1x MI355X"): the reference's case1 test image centred on a
+1024 x 1024 BGR canvas, 360 case1 rotation templates (131 / 71 features) per GPU, pyramid {4, 8}, threshold 90.
+--batch frames per step (default 16: sbm_match_batch_device launches every kernel once for the batch; frame b is the
+workload frame shifted 8*b columns) and --inflight independent slots (contexts + streams, default 2) used
+round-robin.  The same line also carries the fully textured frame and the SURVEY 8d Stage-A frame (shapes + noise)
+as secondary, separately timed passes (config.textured_us_per_frame, config.stage_a_us_per_frame).
+
+Other BASELINE configurations (not the driver's line; --config):
+  c3  2048^2, 3600 templates x 63/31 features          template loop on Stage-B maps, template-sharded
+  c4  4096^2, 36 000 templates x 8191/4095 features    template loop on Stage-B maps, template-sharded
+  c5  64 x (1920 x 1072) BGR frames, 1000 templates    whole match(), FRAME-sharded (rank r takes frames r::N)
+--scaling weak (default: the per-GPU work is fixed) | strong (the total work is fixed and divided over the ranks).
 
 Prints ONE JSON line on rank 0.
 """
@@ -32,59 +34,118 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
-ROWS = COLS = 1024
-N_TEMPLATES = 360
 THRESHOLD = 90.0
 T_LEVELS = (4, 8)
 PREFETCH = 256  # capacity (records) of the per-frame match list exchanged between ranks / sent to the host
 
 
-def load_workload(world: int, frame_kind: str = "case1"):
-    from shape_based_matching_amd import synth
+# ---------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------
+def case1_templates(n):
     from shape_based_matching_amd.templates import TemplateSet
 
-    golden = os.path.join(ROOT, "tests", "golden")
-    base = TemplateSet.load_npz(os.path.join(golden, "case1_templates.npz")).subset(range(N_TEMPLATES))
-    shards = []
-    for r in range(world):
-        s = base.subset(range(N_TEMPLATES))
-        s.class_ids = [f"test{r}"]
-        shards.append(s)
-    ts = TemplateSet.concat(shards)
-    img = np.load(os.path.join(golden, "case1_test_bgr.npz"))["bgr"]
-    if frame_kind == "tiled":
-        # no constant region anywhere: the test image repeated over the whole canvas (robustness figure,
-        # none of k_quantize's flat-tile shortcuts fire)
-        reps = (-(-ROWS // img.shape[0]), -(-COLS // img.shape[1]), 1)
-        frame = np.ascontiguousarray(np.tile(img, reps)[:ROWS, :COLS])
-    else:
-        frame = synth.embed(img, ROWS, COLS, (ROWS - img.shape[0]) // 2, (COLS - img.shape[1]) // 2)
-    return ts, frame
+    base = TemplateSet.load_npz(os.path.join(ROOT, "tests", "golden", "case1_templates.npz"))
+    sets, k = [], 0
+    while n > 0:
+        take = min(n, 360)
+        s = base.subset(range(take))
+        s.class_ids = [f"test{k}"]
+        sets.append(s)
+        n -= take
+        k += 1
+    return TemplateSet.concat(sets)
+
+
+def case1_frame(kind, rows, cols):
+    """case1: the reference's test image centred on a black canvas (test.cpp:344-353 pads it the same way);
+    tiled: the image repeated over the whole canvas (no constant region anywhere);
+    stagea: SURVEY 8d's Stage-A input — black background, random filled rectangles / ellipses, noise in [-2, 2]."""
+    from shape_based_matching_amd import synth
+
+    img = np.load(os.path.join(ROOT, "tests", "golden", "case1_test_bgr.npz"))["bgr"]
+    if kind == "tiled":
+        reps = (-(-rows // img.shape[0]), -(-cols // img.shape[1]), 1)
+        return np.ascontiguousarray(np.tile(img, reps)[:rows, :cols])
+    if kind == "stagea":
+        return synth.scene_bgr(1234, rows, cols)
+    return synth.embed(img, rows, cols, (rows - img.shape[0]) // 2, (cols - img.shape[1]) // 2)
+
+
+class Workload:
+    """What a step does.  stage = "match": whole match() of `frames` (uint8 [B, rows, cols(, 3)]);
+    stage = "templates": the template loop on Stage-B orientation maps that are uploaded once."""
+
+
+def make_workload(args, world):
+    from shape_based_matching_amd import synth
+
+    w = Workload()
+    w.name, w.scaling = args.config, args.scaling
+    w.shard = "templates"
+    w.maps = None
+    if args.config == "case1":
+        w.rows = w.cols = 1024
+        w.ch, w.stage = 3, "match"
+        per = args.templates or 360
+        w.ts = case1_templates(per * world if args.scaling == "weak" else per)
+        w.batch = max(1, args.batch)
+        frame = case1_frame(args.frame, w.rows, w.cols)
+        w.frames = np.stack([np.roll(frame, 8 * b, axis=1) for b in range(w.batch)])
+        w.desc = (f"case1 on MI355X: 1024x1024x3 frames x {per} templates {'per GPU' if args.scaling == 'weak' else 'in total'} "
+                  f"(131/71 features), pyramid T={{4,8}}, threshold 90, {w.batch} frame(s) per step, every frame's match list "
+                  "gathered to the host every step")
+        w.data = {"case1": "reference case1 test image (test/case1/test.png) centred on a black 1024x1024 BGR canvas; ",
+                  "tiled": "reference case1 test image (test/case1/test.png) tiled over the whole 1024x1024 BGR canvas; ",
+                  "stagea": "SURVEY 8d Stage-A scene (random shapes + noise) 1024x1024 BGR; "}[args.frame] + \
+            "case1 rotation templates 0..359 (test/case1/test_templ.yaml)"
+    elif args.config in ("c3", "c4"):
+        w.rows = w.cols = 2048 if args.config == "c3" else 4096
+        w.ch, w.stage, w.batch = 1, "templates", 1
+        nf, box, total = ([63, 31], 260, 3600) if args.config == "c3" else ([8191, 4095], 1024, 36000)
+        total = args.templates or total
+        n = total * world if args.scaling == "weak" else total
+        w.maps, w.ts = synth.stage_b(1234, w.rows, w.cols, T_LEVELS, n, nf, templ_size=box, plant_every=40)
+        w.frames = None
+        w.desc = (f"BASELINE config {args.config[1]}: {w.rows}x{w.cols} Stage-B orientation maps (2 % one-hot density, every 40th "
+                  f"template planted), {n} templates x {nf[0]}/{nf[1]} features, template loop (coarse pass + refinement) per step")
+        w.data = "synthetic Stage-B inputs (SURVEY 8d), seed 1234"
+    else:  # c5
+        w.rows, w.cols, w.ch, w.stage = 1072, 1920, 3, "match"
+        w.shard = "frames"
+        total_frames = args.batch if args.batch != 16 else 64
+        w.total_frames = total_frames * world if args.scaling == "weak" else total_frames
+        w.ts = case1_templates(args.templates or 1000)
+        frame = case1_frame("tiled", w.rows, w.cols)
+        w.frames = np.stack([np.roll(frame, 8 * b, axis=1) for b in range(w.total_frames)])
+        w.batch = None  # per rank, set by the caller
+        w.desc = (f"BASELINE config 5: {w.total_frames} x (1920x1072x3) frames (the 1080p frame cropped to multiples of 16), "
+                  f"{w.ts.n_templates} templates (131/71 features), frame-sharded: rank r matches frames r::N, one gather of the lists")
+        w.data = "reference case1 test image tiled over 1920x1072; case1 rotation templates repeated to 1000"
+    return w
 
 
 def cpu_baseline(ts, frame, budget_s: float = 12.0):
     """The CPU oracle (a port of the reference algorithm, OpenMP over templates like
-    line2Dup.cpp:1166-1170) timed on this host on the same frame and templates."""
+    line2Dup.cpp:1166-1170) timed on this host on the same frame and templates.  Returns (json dict, match list)."""
     from oracle import oracle as O
 
     ncpu = os.cpu_count() or 1
+    last = [None]
 
     def run(threads, reps):
         t0 = time.perf_counter()
-        n = 0
         for _ in range(reps):
             pyr = O.Pyramid.build(frame, list(T_LEVELS), 30.0)
-            recs = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, THRESHOLD, n_threads=threads)
-            n = len(recs)
+            last[0] = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, THRESHOLD, n_threads=threads)
             pyr.free()
-        return (time.perf_counter() - t0) / reps, n
+        return (time.perf_counter() - t0) / reps
 
-    t1, n1 = run(1, 2)
-    tn, _ = run(ncpu, 2) if ncpu > 1 else (t1, n1)
+    t1 = run(1, 2)
+    tn = run(ncpu, 2) if ncpu > 1 else t1
     threads = 1 if t1 <= tn else ncpu
-    per = min(t1, tn)
-    reps = max(3, int(budget_s / per))
-    per, n = run(threads, reps)
+    reps = max(3, int(budget_s / min(t1, tn)))
+    per = run(threads, reps)
     value = ts.n_templates * (frame.shape[0] * frame.shape[1] / 1e6) / per
     return {
         "value": value,
@@ -92,12 +153,12 @@ def cpu_baseline(ts, frame, budget_s: float = 12.0):
         "cores": threads,
         "kind": "port",
         "sample": f"{reps} full match() calls of the bench frame with {ts.n_templates} templates "
-                  f"({per * 1e3:.1f} ms each, {n} raw matches); host has {ncpu} logical cores",
+                  f"({per * 1e3:.1f} ms each, {len(last[0])} raw matches); host has {ncpu} logical cores",
         "ms_per_match": per * 1e3,
         # both ways of running the reference's OpenMP template loop (always report both)
         "ms_per_match_1_thread": t1 * 1e3,
         "ms_per_match_all_threads": tn * 1e3,
-    }
+    }, last[0]
 
 
 def main():
@@ -115,9 +176,13 @@ def main():
     ap.add_argument("--batch", type=int, default=16,
                     help="frames per step: a step is one sbm_match_batch_device call over this many frames (distinct "
                          "horizontal shifts of the workload frame); 1 = one sbm_match_device call per step")
-    ap.add_argument("--frame", choices=("case1", "tiled"), default="case1",
-                    help="case1: the reference's test image centred on a black canvas (BASELINE configs[1]); "
-                         "tiled: the same image repeated over the whole canvas (no constant regions)")
+    ap.add_argument("--frame", choices=("case1", "tiled", "stagea"), default="case1",
+                    help="case1: the reference's test image centred on a black canvas (BASELINE configs[1]); tiled: the same "
+                         "image repeated over the whole canvas; stagea: SURVEY 8d's shapes + noise scene")
+    ap.add_argument("--config", choices=("case1", "c3", "c4", "c5"), default="case1")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--templates", type=int, default=0, help="override the configuration's template count")
+    ap.add_argument("--no-extra-frames", action="store_true", help="skip the secondary (textured / Stage-A) passes")
     args = ap.parse_args()
 
     import torch
@@ -142,42 +207,51 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    ts, frame = load_workload(world, args.frame)
-    first, count = sharding.partition(sharding.coarse_work(ts, ROWS, COLS, T_LEVELS), world)[rank]
-
-    cap = PREFETCH
-    B = max(1, args.batch)
-    # frame b of a batch = the workload frame rolled b * 8 columns (same content, same work, different bytes)
-    batch_frames = np.stack([np.roll(frame, 8 * b, axis=1) for b in range(B)])
-    d_img = torch.from_numpy(batch_frames).to(dev)
-    FRAME_BYTES = ROWS * COLS * 3
+    wl = make_workload(args, world)
+    ts = wl.ts
+    ROWS, COLS, CH = wl.rows, wl.cols, wl.ch
+    if wl.shard == "templates":
+        first, count = sharding.partition(sharding.coarse_work(ts, ROWS, COLS, T_LEVELS), world)[rank]
+        my_frames = np.arange(wl.batch) if wl.frames is not None else None
+    else:  # frames dealt rank::world, templates replicated
+        first, count = 0, ts.n_templates
+        my_frames = sharding.frame_shard(wl.total_frames, world, rank)
+    B = len(my_frames) if my_frames is not None else 1
+    cap = (PREFETCH if args.config == "case1" else 2048) if wl.stage == "match" else 4096
+    FRAME_BYTES = ROWS * COLS * CH
+    d_img = torch.from_numpy(np.ascontiguousarray(wl.frames[my_frames])).to(dev) if wl.frames is not None else None
 
     REC = MATCH_DTYPE.itemsize
     # per rank: B {n_matches, overflow} int32 pairs (padded to 16 bytes) in front of B blocks of cap records:
     # one buffer, one collective, one copy
     HDR = (8 * B + 15) // 16 * 16
     BUF = HDR + B * cap * REC
+    native_gather = collective and wl.stage == "match"  # the library issues ncclAllGather on the kernels' stream
 
     class Slot:
-        """one frame in flight: its own engine context (device buffers), stream and result buffers"""
+        """one step in flight: its own engine context (device buffers), stream and result buffers"""
 
-        def __init__(self, main_stream):
-            self.ctx = capi.Context(T=T_LEVELS, weak_threshold=30.0, device_id=local_rank)
+        def __init__(self):
+            self.ctx = capi.Context(T=T_LEVELS, weak_threshold=30.0, device_id=local_rank,
+                                    max_candidates=0 if wl.stage == "match" else 1 << 22)
             self.ctx.upload_templates(ts)
             self.ctx.select_range(first, count)
             if os.environ.get("SBM_GRAPH"):
                 self.ctx.set_graph_mode(True)
+            if wl.maps is not None:
+                for l in range(len(T_LEVELS)):
+                    self.ctx.set_quantized(l, wl.maps[l])
             # always an explicit stream: handle 0 would mean "the context's own stream" to the C ABI and
             # the result copies below must be ordered after the kernels
             self.stream = torch.cuda.Stream(device=dev)
-            self.d_buf = torch.zeros(BUF, dtype=torch.uint8, device=dev)       # this rank: header + records
+            self.d_buf = torch.zeros(BUF, dtype=torch.uint8, device=dev)          # this rank: header + records
             self.g_buf = torch.zeros(world * BUF, dtype=torch.uint8, device=dev)  # all ranks, gathered
             self.h_buf = torch.zeros(world * BUF, dtype=torch.uint8).pin_memory()
             if not collective:
                 # single GPU: the last kernel stores the match list straight into pinned host memory
                 self.ctx.set_result_mirror(self.h_buf.data_ptr() + HDR, self.h_buf.data_ptr())
-            else:
-                # one RCCL communicator per frame slot, bootstrapped over torch.distributed
+            elif native_gather:
+                # one RCCL communicator per slot, bootstrapped over torch.distributed
                 uid = torch.zeros(128, dtype=torch.uint8, device=dev)
                 if rank == 0:
                     uid.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
@@ -185,22 +259,28 @@ def main():
                 self.ctx.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
 
         def run(self):
-            if collective and B > 1:
-                self.ctx.match_batch_device_sharded(d_img.data_ptr(), FRAME_BYTES, B, ROWS, COLS, COLS * 3, 3, THRESHOLD,
+            s = self.stream.cuda_stream
+            if wl.stage == "templates":
+                self.ctx.match_templates_device(THRESHOLD, self.d_buf.data_ptr() + HDR, cap, self.d_buf.data_ptr(), stream=s)
+                if collective:  # template-loop configs: the exchange through torch.distributed (RCCL) on the same stream
+                    with torch.cuda.stream(self.stream):
+                        dist.all_gather_into_tensor(self.g_buf, self.d_buf)
+                        self.h_buf.copy_(self.g_buf, non_blocking=True)
+            elif native_gather and B > 1:
+                self.ctx.match_batch_device_sharded(d_img.data_ptr(), FRAME_BYTES, B, ROWS, COLS, COLS * CH, CH, THRESHOLD,
                                                     self.d_buf.data_ptr(), cap, self.g_buf.data_ptr(),
-                                                    gathered_mirror=self.h_buf.data_ptr(), stream=self.stream.cuda_stream)
-            elif collective:
-                # match of this rank's template shard + the exchange step (ncclAllGather over xGMI, issued by the
-                # library on the same stream) + copy of the gathered lists into pinned host memory
-                self.ctx.match_device_sharded(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, self.d_buf.data_ptr(), cap,
-                                              self.g_buf.data_ptr(), gathered_mirror=self.h_buf.data_ptr(),
-                                              stream=self.stream.cuda_stream)
+                                                    gathered_mirror=self.h_buf.data_ptr(), stream=s)
+            elif native_gather:
+                # match of this rank's shard + the exchange step (ncclAllGather over xGMI, issued by the library on the
+                # same stream) + copy of the gathered lists into pinned host memory
+                self.ctx.match_device_sharded(d_img.data_ptr(), ROWS, COLS, COLS * CH, CH, THRESHOLD, self.d_buf.data_ptr(), cap,
+                                              self.g_buf.data_ptr(), gathered_mirror=self.h_buf.data_ptr(), stream=s)
             elif B > 1:
-                self.ctx.match_batch_device(d_img.data_ptr(), FRAME_BYTES, B, ROWS, COLS, COLS * 3, 3, THRESHOLD,
-                                            self.d_buf.data_ptr() + HDR, cap, self.d_buf.data_ptr(), stream=self.stream.cuda_stream)
+                self.ctx.match_batch_device(d_img.data_ptr(), FRAME_BYTES, B, ROWS, COLS, COLS * CH, CH, THRESHOLD,
+                                            self.d_buf.data_ptr() + HDR, cap, self.d_buf.data_ptr(), stream=s)
             else:
-                self.ctx.match_device(d_img.data_ptr(), ROWS, COLS, COLS * 3, 3, THRESHOLD, self.d_buf.data_ptr() + HDR, cap,
-                                      self.d_buf.data_ptr(), stream=self.stream.cuda_stream)
+                self.ctx.match_device(d_img.data_ptr(), ROWS, COLS, COLS * CH, CH, THRESHOLD, self.d_buf.data_ptr() + HDR, cap,
+                                      self.d_buf.data_ptr(), stream=s)
 
         def host_counts(self):
             """[world][B][2] = {n_matches, overflow} per rank and frame of the step"""
@@ -210,9 +290,8 @@ def main():
             """[world][B][cap] match records"""
             return self.h_buf.numpy().reshape(world, BUF)[:, HDR:].copy().view(MATCH_DTYPE).reshape(world, B, cap)
 
-    slots = [Slot(None) for i in range(max(1, args.inflight))]
+    slots = [Slot() for _ in range(max(1, args.inflight))]
     ctx = slots[0].ctx
-    stream = slots[0].stream
     torch.cuda.synchronize()
     step_no = [0]
 
@@ -226,30 +305,27 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if collective:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed(n_warm, n_steps, which=None):
+        """K steps bracketed by barrier + synchronize; max over ranks"""
+        run = step if which is None else which
+        for _ in range(n_warm):
+            run()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            run()
+        fence()
+        el = time.perf_counter() - t0
+        if collective:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
 
-    # one frame at a time on one stream (latency-bound figure), same K steps, outside the timed region
-    single_ms = None
-    if len(slots) > 1:
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            slots[0].run()
-        fence()
-        single_ms = (time.perf_counter() - t1) / args.steps * 1e3
-    else:
-        single_ms = elapsed / args.steps * 1e3
+    elapsed = timed(args.warmup, args.steps)
+
+    # one step at a time on one stream (latency-bound figure), same K steps, outside the timed region
+    single_ms = timed(0, args.steps, slots[0].run) / args.steps * 1e3 if len(slots) > 1 else elapsed / args.steps * 1e3
 
     # every slot must hold the same, stable match list (checked outside the timed region)
     ref_counts = None
@@ -257,11 +333,11 @@ def main():
         for sl in slots:
             sl.h_buf.zero_()
             sl.run()
-            torch.cuda.synchronize()
+            fence()
             c = sl.host_counts()
             if ref_counts is None:
                 ref_counts = c
-            if not np.array_equal(c, ref_counts) or c[:, :, 0].min() <= 0:
+            if not np.array_equal(c, ref_counts) or (wl.stage == "match" and args.config == "case1" and c[:, :, 0].min() <= 0):
                 raise SystemExit(f"unstable match counts: {c.tolist()} vs {ref_counts.tolist()}")
     counts = slots[0].host_counts()
     if (counts[:, :, 1] != 0).any() or (counts[:, :, 0] > cap).any():
@@ -272,9 +348,9 @@ def main():
         one_out = torch.zeros(cap * REC, dtype=torch.uint8, device=dev)
         one_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
         ctx.set_result_mirror(0, 0)
-        for b in range(B):
-            ctx.match_device(d_img.data_ptr() + b * FRAME_BYTES, ROWS, COLS, COLS * 3, 3, THRESHOLD, one_out.data_ptr(), cap,
-                             one_cnt.data_ptr(), stream=stream.cuda_stream)
+        for b in range(min(B, 16)):
+            ctx.match_device(d_img.data_ptr() + b * FRAME_BYTES, ROWS, COLS, COLS * CH, CH, THRESHOLD, one_out.data_ptr(), cap,
+                             one_cnt.data_ptr(), stream=slots[0].stream.cuda_stream)
             torch.cuda.synchronize()
             n1 = int(one_cnt.cpu().numpy()[0])
             single = capi.canonicalize(one_out.cpu().numpy().view(MATCH_DTYPE)[:n1].copy())
@@ -282,25 +358,56 @@ def main():
             if n1 != counts[0, b, 0] or single.tobytes() != batched.tobytes():
                 raise SystemExit(f"frame {b} of the batch differs from its single-frame match list")
         ctx.set_result_mirror(slots[0].h_buf.data_ptr() + HDR, slots[0].h_buf.data_ptr())
-    # frame 0 of the step: every rank's list, gathered
-    matches = np.concatenate([recs[r, 0, : counts[r, 0, 0]] for r in range(world)])
-    n_matches = len(capi.canonicalize(matches))
+    # frame 0 of the step: every rank's list, gathered (frame-sharded: rank 0's first frame)
+    src_ranks = range(world) if wl.shard == "templates" else range(1)
+    matches = np.concatenate([recs[r, 0, : counts[r, 0, 0]] for r in src_ranks])
+    n_matches = len(capi.canonicalize(matches.copy()))
 
     # per-kernel durations: a second pass of the same steps on ONE slot (its stream runs the kernels back to back with
     # nothing synchronised in between, so a kernel's duration is its own: with two slots the kernels of the two steps
     # overlap on the GPU and stretch each other), timed with the dispatch packets' own start/stop timestamps
     # (hipExtLaunchKernelGGL events on the launch stream); kept out of the timed region above
-    slots[0].ctx.set_profiling(True, accumulate=True)
-    per_kernel = {}
+    def kernel_pass(n):
+        slots[0].ctx.set_profiling(True, accumulate=True)
+        per = {}
+        for _ in range(n):
+            slots[0].run()
+        fence()
+        for name, ms in slots[0].ctx.timings():
+            per.setdefault(name, []).append(ms)
+        slots[0].ctx.set_profiling(False)
+        out = {}
+        for name, v in per.items():
+            launches = len(v) // n
+            a = np.asarray(v).reshape(n, launches)
+            out[name] = {"ms_per_step": float(a.sum(axis=1).mean()), "launches": launches, "avg_launch_us": float(a.mean() * 1e3),
+                         # the launches of a step in order (k_quantize: pyramid level 0, level 1, ...)
+                         "launch_us": [float(x) for x in a.mean(axis=0) * 1e3]}
+        return out
+
     prof_steps = min(args.steps, 50)
-    for rep in range(prof_steps):
-        slots[0].run()
-    fence()
-    for name, ms in slots[0].ctx.timings():
-        per_kernel.setdefault(name, []).append(ms)
-    slots[0].ctx.set_profiling(False)
+    kern = kernel_pass(prof_steps)
     n_cand, refine_bytes = ctx.stats()
     coarse_bytes = ctx.coarse_bytes()
+
+    # secondary frames of the default workload: same engine, same templates, other pixels (separately timed)
+    extra = {}
+    if args.config == "case1" and args.frame == "case1" and not args.no_extra_frames and wl.stage == "match":
+        keep = d_img.clone()
+        for kind, key in (("tiled", "textured"), ("stagea", "stage_a")):
+            fr = case1_frame(kind, ROWS, COLS)
+            d_img.copy_(torch.from_numpy(np.stack([np.roll(fr, 8 * b, axis=1) for b in range(B)])).to(dev))
+            n = max(20, min(args.steps, 300))
+            el = timed(max(5, n // 10), n)
+            k2 = kernel_pass(min(n, 30))
+            fence()
+            c2 = slots[0].host_counts()
+            extra[key] = {"us_per_frame": el / n / B * 1e6, "steps": n,
+                          "matches_frame0": int(c2[:, 0, 0].sum()),
+                          "kernel_launch_us": {k: [round(x, 2) for x in v["launch_us"]] for k, v in k2.items()}}
+        d_img.copy_(keep)
+        slots[0].run()
+        fence()
 
     if rank == 0:
         # algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md), by kernel
@@ -308,19 +415,19 @@ def main():
         alg = {
             # frame read + one-hot map written (+ the next level's image, written by the fused pyrDown);
             # a launch covers the B frames of the step (refinement bytes: frame 0's figure x B)
-            "k_quantize": [B * (npx[0] * (3 + 1) + npx[1] * 3), B * npx[1] * (3 + 1)],
+            "k_quantize": [B * (npx[0] * (CH + 1) + npx[1] * CH), B * npx[1] * (CH + 1)],
             "k_build_lm": [B * sum(n * 9 for n in npx)],
             "k_similarity_coarse": [B * coarse_bytes],
             "k_similarity_local": [B * refine_bytes],
         }
-        kern = {}
-        for name, v in per_kernel.items():
-            launches = len(v) // prof_steps
-            a = np.asarray(v).reshape(prof_steps, launches)
-            kern[name] = {"ms_per_step": float(a.sum(axis=1).mean()), "launches": launches,
-                          "avg_launch_us": float(a.mean() * 1e3),
-                          # the launches of a step in order (k_quantize: pyramid level 0, level 1, ...)
-                          "launch_us": [float(x) for x in a.mean(axis=0) * 1e3]}
+        limiter = {
+            "k_quantize": "vector-instruction issue (integer VALU at one wave-instruction per 4 cycles per SIMD); HBM traffic "
+                          "equals the algorithmic bytes",
+            "k_build_lm": "HBM writes of the linear memories",
+            "k_similarity_coarse": "L2 -> L1 bandwidth: the linear memories are re-read from the cache hierarchy by every template",
+            "k_similarity_local": "L2 line traffic of the 16x16 patch reads + vector issue of the response LUT",
+        }
+        for name in kern:
             if name in alg:
                 kern[name]["algorithmic_bytes_per_step"] = float(sum(alg[name]))
                 kern[name]["achieved_GBps"] = float(sum(alg[name])) / (kern[name]["ms_per_step"] * 1e-3) / 1e9
@@ -330,16 +437,46 @@ def main():
         achieved = dom_bytes / dom_s / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.config == "case1":
             try:
                 traffic = json.load(open(pmc)).get(dom)
             except Exception:
                 traffic = None
-        step_bytes = float(sum(sum(v) for v in alg.values()))
+        step_bytes = float(sum(sum(v) for k, v in alg.items() if k in kern))
         total_templates = ts.n_templates
-        value = total_templates * (ROWS * COLS / 1e6) * B * args.steps / elapsed
+        frames_per_step_total = (wl.total_frames if wl.shard == "frames" else B)
+        value = total_templates * (ROWS * COLS / 1e6) * frames_per_step_total * args.steps / elapsed
+        cfg = {
+            "workload": wl.desc,
+            "stage": "whole Detector::match per frame" if wl.stage == "match" else "template loop (matchClass) on resident Stage-B pyramids",
+            "templates_total": total_templates,
+            "templates_per_gpu": count,
+            "frame": [ROWS, COLS, CH],
+            "parallelism": (f"template-shard x{world}" if wl.shard == "templates" else f"frame-shard x{world}")
+                           + (" + RCCL all-gather of match lists" if collective else ""),
+            "frames_per_step": frames_per_step_total,
+            "frames_per_step_per_gpu": B,
+            "us_per_frame": elapsed / args.steps / frames_per_step_total * 1e6,
+            "frames_in_flight": len(slots) * B,
+            ("ms_per_step_one_frame_at_a_time" if B == 1 else "ms_per_step_one_batch_at_a_time"): single_ms,
+            # SURVEY 8d's two times per frame, from the per-kernel pass (kernels alone on one stream):
+            # t_match = all kernels, t_templ = the template loop (coarse + refinement) only
+            "t_match_kernels_us_per_frame": sum(v["ms_per_step"] for v in kern.values()) * 1e3 / B,
+            "t_templ_kernels_us_per_frame": sum(v["ms_per_step"] for k, v in kern.items() if k.startswith("k_similarity")) * 1e3 / B,
+            "matches_distinct": n_matches,
+            "coarse_candidates_rank0": n_cand,
+        }
+        if extra:
+            # the same step on a frame without constant regions and on the SURVEY 8d Stage-A scene: `value` is the
+            # BASELINE configuration (65 % of its canvas is constant), these are the content-independent figures
+            cfg["textured_us_per_frame"] = extra["textured"]["us_per_frame"]
+            cfg["stage_a_us_per_frame"] = extra["stage_a"]["us_per_frame"]
+            cfg["value_textured"] = total_templates * (ROWS * COLS / 1e6) / (extra["textured"]["us_per_frame"] * 1e-6)
+            cfg["value_stage_a"] = total_templates * (ROWS * COLS / 1e6) / (extra["stage_a"]["us_per_frame"] * 1e-6)
+            cfg["other_frames"] = extra
         out = {
-            "metric": "templates*Mpixels/sec (whole Detector::match, frame resident in HBM)",
+            "metric": "templates*Mpixels/sec (whole Detector::match, frame resident in HBM)" if wl.stage == "match"
+                      else "templates*Mpixels/sec (template loop only, pyramid resident)",
             "value": value,
             "unit": "templates*Mpixels/s",
             "n_gpus": world,
@@ -347,34 +484,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8",
-            "data": ("reference case1 test image (test/case1/test.png) centred on a black 1024x1024 BGR canvas; "
-                     if args.frame == "case1" else
-                     "reference case1 test image (test/case1/test.png) tiled over the whole 1024x1024 BGR canvas; ")
-                    + "case1 rotation templates 0..359 (test/case1/test_templ.yaml)",
-            "config": {
-                "workload": "case1 on MI355X: 1024x1024x3 frames x 360 templates per GPU (131/71 features), "
-                            f"pyramid T={{4,8}}, threshold 90, {B} frame(s) per step, every frame's match list gathered "
-                            "to the host every step",
-                "templates_total": total_templates,
-                "templates_per_gpu": count,
-                "frame": [ROWS, COLS, 3],
-                "parallelism": f"template-shard x{world}" + (" + RCCL all-gather of match lists" if collective else ""),
-                "frames_per_step": B,
-                "us_per_frame": elapsed / args.steps / B * 1e6,
-                "frames_in_flight": len(slots) * B,
-                ("ms_per_step_one_frame_at_a_time" if B == 1 else "ms_per_step_one_batch_at_a_time"): single_ms,
-                # SURVEY 8d's two times per frame, from the per-kernel pass (kernels alone on one stream):
-                # t_match = all five kernels, t_templ = the template loop (coarse + refinement) only
-                "t_match_kernels_us_per_frame": sum(v["ms_per_step"] for v in kern.values()) * 1e3 / B,
-                "t_templ_kernels_us_per_frame": sum(v["ms_per_step"] for k, v in kern.items() if k.startswith("k_similarity")) * 1e3 / B,
-                "matches_distinct": n_matches,
-                "coarse_candidates_rank0": n_cand,
-            },
+            "data": wl.data,
+            "config": cfg,
             "roofline": {
                 "bound": "hbm",
+                "limiter": limiter.get(dom, ""),
                 "kernel": dom,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -384,18 +501,25 @@ def main():
                 "algorithmic_bytes_per_launch": dom_bytes,
                 "avg_launch_us": kern[dom]["avg_launch_us"],
                 "note": "per launch = the frames of one step; figures are the mean over this kernel's launches of a step "
-                        "(k_quantize: one launch per pyramid level).  Per 1-Mpixel frame every kernel moves <= 10 MB from "
-                        "HBM (<= 1.3 us at 8 TB/s); k_quantize is VALU/latency-bound, k_similarity_coarse streams its "
-                        "72 MB per frame of algorithmic bytes from the L2-resident linear memories",
+                        "(k_quantize: one launch per pyramid level).  `bound` names the roofline the fraction is taken against "
+                        "(HBM, as BASELINE's north_star asks); `limiter` is what the counters say actually bounds the kernel",
                 "whole_step": {"algorithmic_bytes": step_bytes,
                                "achieved": step_bytes / (elapsed / args.steps) / 1e9,
                                "frac": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
             },
             "kernels": kern,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and wl.stage == "match":
             base_ts = ts.subset(range(first, first + count))
-            out["cpu_baseline"] = cpu_baseline(base_ts, frame, args.cpu_budget)
+            if base_ts.n_templates > 360:  # a bounded sample of the same workload
+                base_ts = base_ts.subset(range(360))
+            frame0 = np.ascontiguousarray(wl.frames[my_frames[0]])
+            out["cpu_baseline"], cpu_list = cpu_baseline(base_ts, frame0, args.cpu_budget)
+            if base_ts.n_templates == count:
+                # the checker's list for frame 0 must be the GPU's (outside every timed region)
+                if capi.canonicalize(np.ascontiguousarray(cpu_list, MATCH_DTYPE).copy()).tobytes() != capi.canonicalize(matches.copy()).tobytes():
+                    raise SystemExit("GPU match list of frame 0 differs from the CPU oracle's")
+                out["cpu_baseline"]["gpu_list_equals_cpu_list"] = True
         print(json.dumps(out))
     for sl in slots:
         sl.ctx.close()

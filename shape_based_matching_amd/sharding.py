@@ -79,3 +79,39 @@ def all_gather_matches(recs, count, group=None):
     g = gathered.cpu().numpy().view(MATCH_DTYPE).reshape(world, cap)
     out = np.concatenate([g[r, : counts_h[r, 0]] for r in range(world)]) if world else np.zeros(0, MATCH_DTYPE)
     return out, counts_h[:, 0].copy()
+
+
+# ---- frame sharding (BASELINE config 5: a stream of frames, templates replicated) ------------------------------
+def frame_shard(n_frames: int, world: int, rank: int) -> np.ndarray:
+    """Frames of a batch owned by ``rank``: rank, rank + world, ...  Frames are independent
+    (``Detector::match`` keeps no state between calls, line2Dup.cpp:1078-1150), so nothing is exchanged
+    until the per-frame match lists are gathered."""
+    return np.arange(rank, n_frames, world, dtype=np.int64)
+
+
+def all_gather_frame_lists(recs, counts, n_frames: int, group=None):
+    """One gather for a frame-sharded batch.
+
+    ``recs``: torch uint8 ``[per_rank * cap * 24]`` — the rank's frames in shard order, ``cap`` records each;
+    ``counts``: torch int32 ``[per_rank * 2]`` ({n_matches, overflow} per frame); every rank passes the same
+    ``per_rank = ceil(n_frames / world)`` (ranks with one frame less leave the last slot's count at 0).
+    Returns a list of ``n_frames`` numpy record arrays in frame order."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    per_rank = counts.numel() // 2
+    cap = recs.numel() // (per_rank * MATCH_DTYPE.itemsize)
+    g_counts = torch.empty(world * counts.numel(), dtype=counts.dtype, device=counts.device)
+    dist.all_gather_into_tensor(g_counts, counts, group=group)
+    g_recs = torch.empty(world * recs.numel(), dtype=recs.dtype, device=recs.device)
+    dist.all_gather_into_tensor(g_recs, recs, group=group)
+    c = g_counts.cpu().numpy().reshape(world, per_rank, 2)
+    r = g_recs.cpu().numpy().view(MATCH_DTYPE).reshape(world, per_rank, cap)
+    out = []
+    for f in range(n_frames):
+        rk, slot = f % world, f // world
+        if c[rk, slot, 1] != 0 or c[rk, slot, 0] > cap:
+            raise RuntimeError(f"match list of frame {f} overflowed on rank {rk}: {c[rk, slot].tolist()} cap={cap}")
+        out.append(r[rk, slot, : c[rk, slot, 0]].copy())
+    return out

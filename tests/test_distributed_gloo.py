@@ -69,6 +69,56 @@ def test_template_shards_all_gather_world2(tmp_path, oracle):
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
 
 
+def _frame_worker(rank, world, port, out_dir):
+    """BASELINE config 5 on CPU: the frames of a batch dealt rank::world, templates replicated, one gather of the
+    per-frame lists; the oracle stands in for the per-rank engine."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from shape_based_matching_amd import sharding, synth
+        from shape_based_matching_amd.templates import MATCH_DTYPE, TemplateSet
+
+        golden = os.path.join(ROOT, "tests", "golden")
+        ts = TemplateSet.load_npz(os.path.join(golden, "case1_templates.npz")).subset(range(300, 361, 5))
+        img = np.load(os.path.join(golden, "case1_test_bgr.npz"))["bgr"]
+        base = synth.embed(img, 640, 768, 80, 80)
+        n_frames = 5  # not a multiple of the world size: the last rank slot stays empty
+        frames = [np.roll(base, 24 * f, axis=1) for f in range(n_frames)]
+        mine = sharding.frame_shard(n_frames, world, rank)
+        assert mine.tolist() == list(range(rank, n_frames, world))
+        per_rank = -(-n_frames // world)
+        cap = 512
+        recs = np.zeros((per_rank, cap), MATCH_DTYPE)
+        counts = np.zeros((per_rank, 2), np.int32)
+        for slot, f in enumerate(mine):
+            pyr = O.Pyramid.build(frames[f], [4, 8], 30.0)
+            got = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 85.0)
+            pyr.free()
+            recs[slot, : len(got)] = got
+            counts[slot, 0] = len(got)
+        lists = sharding.all_gather_frame_lists(torch.from_numpy(recs.view(np.uint8).reshape(-1).copy()),
+                                                torch.from_numpy(counts.reshape(-1).copy()), n_frames)
+        assert len(lists) == n_frames
+        for f in range(n_frames):
+            pyr = O.Pyramid.build(frames[f], [4, 8], 30.0)
+            want = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 85.0)
+            pyr.free()
+            assert len(want) > 0
+            assert O.canonicalize(lists[f]).tobytes() == O.canonicalize(want).tobytes(), f
+        open(os.path.join(out_dir, f"fok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_shards_gather_world2(tmp_path, oracle):
+    world = 2
+    mp.spawn(_frame_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"fok{r}") for r in range(world))
+
+
 def test_partition_properties():
     from shape_based_matching_amd import sharding
 
