@@ -40,6 +40,21 @@
 
 struct sbm_ctx; /* include/sbm.h */
 
+/* The reference's header pulls in its CPU SIMD wrapper (MIPP/mipp.h, line2Dup.h:10) and its MIPP_test demo prints
+ * these constants (test.cpp:530-536).  This engine has no CPU SIMD layer — the hot loops are HIP kernels — so the
+ * names exist only to keep such callers compiling; they describe the device the work runs on. */
+namespace mipp {
+static const std::string InstructionType = "HIP";
+static const std::string InstructionFullType = "HIP gfx950 (CDNA4), wave64";
+static const std::string InstructionVersion = "1";
+static const int RegisterSizeBit = 64 * 32; /* one VGPR of a 64-lane wavefront */
+static const int Lanes = 1;
+static const bool Support64Bit = true;
+static const bool SupportByteWord = true;
+} // namespace mipp
+#define has_max_int8_t 1   /* v_pk_max / SWAR byte maxima in the kernels */
+#define has_shuff_int8_t 1 /* v_perm_b32 */
+
 namespace line2Dup {
 
 /* line2Dup.h:116-129 */

@@ -215,6 +215,11 @@ int sbm_quantized_orientations(sbm_ctx* ctx, const uint8_t* img_host, int32_t ro
  * phase image) as the match path computes it: an integer rule on the Sobel gradient (gx, gy), exact for
  * |gx|, |gy| <= 1020.  q16[i] in 0..16. */
 int sbm_orientation_bins(sbm_ctx* ctx, const int16_t* gx, const int16_t* gy, int64_t n, uint8_t* q16);
+/* cv::resize(src, dst, cv::Size(), fx, fy) (INTER_LINEAR, 8-bit) as shapeInfo_producer::transform calls it to make
+ * the scaled training images (line2Dup.h:379-405).  Output size = (cvRound(rows*fy), cvRound(cols*fx)), written to
+ * out_rows / out_cols; out == NULL only queries the size. */
+int sbm_resize_linear(sbm_ctx* ctx, const uint8_t* img_host, int32_t rows, int32_t cols, int32_t stride, int32_t channels,
+                      double fx, double fy, uint8_t* out, int64_t cap_bytes, int32_t* out_rows, int32_t* out_cols);
 /* cv::pyrDown as called by ColorGradientPyramid::pyrDown (line2Dup.cpp:431-433). */
 int sbm_pyrdown(sbm_ctx* ctx, const uint8_t* img_host, int32_t rows, int32_t cols, int32_t stride,
                 int32_t channels, uint8_t* out_host);

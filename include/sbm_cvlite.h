@@ -14,6 +14,7 @@
 #define SBM_CVLITE_H
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -96,12 +97,14 @@ struct Size_ {
     T area() const { return width * height; }
 };
 typedef Size_<int> Size;
+typedef Size_<float> Size2f;
 
 template <class T>
 struct Point_ {
     T x, y;
     Point_() : x(0), y(0) {}
     Point_(T x_, T y_) : x(x_), y(y_) {}
+    template <class U> Point_(const Point_<U>& o) : x((T)o.x), y((T)o.y) {}
     Point_ operator-(const Point_& o) const { return Point_(x - o.x, y - o.y); }
     Point_ operator+(const Point_& o) const { return Point_(x + o.x, y + o.y); }
     Point_& operator/=(T d) { x /= d; y /= d; return *this; }
@@ -124,10 +127,44 @@ struct Rect_ {
 };
 typedef Rect_<int> Rect;
 
+template <class T, int N>
+struct Vec {
+    T val[N];
+    Vec() { for (int i = 0; i < N; ++i) val[i] = T(); }
+    T& operator[](int i) { return val[i]; }
+    const T& operator[](int i) const { return val[i]; }
+};
+typedef Vec<uchar, 3> Vec3b;
+
 struct Scalar {
     double val[4];
     Scalar(double a = 0, double b = 0, double c = 0, double d = 0) { val[0] = a; val[1] = b; val[2] = c; val[3] = d; }
+    template <class T, int N> Scalar(const Vec<T, N>& v) { for (int i = 0; i < 4; ++i) val[i] = i < N ? (double)v.val[i] : 0.0; }
     static Scalar all(double v) { return Scalar(v, v, v, v); }
+    double& operator[](int i) { return val[i]; }
+    const double& operator[](int i) const { return val[i]; }
+};
+
+/* cv::RotatedRect (the demos draw the matched template's outline with it, test.cpp:402-409) */
+struct RotatedRect {
+    Point2f center;
+    Size2f size;
+    float angle;
+    RotatedRect() : angle(0) {}
+    RotatedRect(const Point2f& c, const Size2f& s, float a) : center(c), size(s), angle(a) {}
+    void points(Point2f pts[]) const
+    {
+        const double ang = angle * 3.14159265358979323846 / 180.;
+        const float b = (float)std::cos(ang) * 0.5f, a = (float)std::sin(ang) * 0.5f;
+        pts[0].x = center.x - a * size.height - b * size.width;
+        pts[0].y = center.y + b * size.height - a * size.width;
+        pts[1].x = center.x + a * size.height - b * size.width;
+        pts[1].y = center.y - b * size.height - a * size.width;
+        pts[2].x = 2 * center.x - pts[0].x;
+        pts[2].y = 2 * center.y - pts[0].y;
+        pts[3].x = 2 * center.x - pts[1].x;
+        pts[3].y = 2 * center.y - pts[1].y;
+    }
 };
 
 /* 2-D container with reference-counted storage; ROI views share the buffer. */
@@ -209,6 +246,9 @@ public:
         if (!(dst.rows == rows && dst.cols == cols && dst.type_ == type_ && dst.data)) dst.create(rows, cols, type_);
         for (int r = 0; r < rows; ++r) memcpy(dst.ptr(r), ptr(r), (size_t)cols * elemSize());
     }
+    /* a temporary ROI view as destination, as cv::OutputArray allows: img.copyTo(padded(Rect(...))) (test.cpp:276) */
+    void copyTo(Mat&& dst) const { Mat& d = dst; copyTo(d); }
+    void copyTo(Mat&& dst, const Mat& mask) const { Mat& d = dst; copyTo(d, mask); }
     void copyTo(Mat& dst, const Mat& mask) const
     {
         if (mask.empty()) { copyTo(dst); return; }
@@ -351,6 +391,45 @@ inline FileStorage& operator<<(FileStorage& fs, const std::vector<int>& v)
     for (int x : v) fs << x;
     return fs.put("]");
 }
+
+/* imgproc / highgui names the reference's demo drivers use (test.cpp).  cvtColor is real; the drawing and window
+ * calls are accepted and do nothing: this build has no display (link the real OpenCV with -DSBM_USE_OPENCV to see
+ * pictures). */
+enum { COLOR_BGR2GRAY = 6, COLOR_GRAY2BGR = 8, FONT_HERSHEY_PLAIN = 1 };
+inline void cvtColor(const Mat& src, Mat& dst, int code)
+{
+    if (code == COLOR_GRAY2BGR) {
+        CV_Assert(src.type() == CV_8UC1);
+        Mat out(src.rows, src.cols, CV_8UC3);
+        for (int r = 0; r < src.rows; ++r)
+            for (int c = 0; c < src.cols; ++c) out.ptr(r)[3 * c] = out.ptr(r)[3 * c + 1] = out.ptr(r)[3 * c + 2] = src.ptr(r)[c];
+        dst = out;
+    } else if (code == COLOR_BGR2GRAY) {
+        CV_Assert(src.type() == CV_8UC3);
+        Mat out(src.rows, src.cols, CV_8UC1);
+        for (int r = 0; r < src.rows; ++r)
+            for (int c = 0; c < src.cols; ++c) {
+                const uchar* p = src.ptr(r) + 3 * c; /* cv::cvtColor 8-bit: (B*1868 + G*9617 + R*4899 + 2^13) >> 14 */
+                out.ptr(r)[c] = (uchar)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14);
+            }
+        dst = out;
+    } else {
+        CV_Error(Error::StsBadArg, "cvtColor: unsupported conversion");
+    }
+}
+enum { INTER_NEAREST = 0, INTER_LINEAR = 1 };
+enum { ROTATE_90_CLOCKWISE = 0, ROTATE_180 = 1, ROTATE_90_COUNTERCLOCKWISE = 2 };
+/* cv::resize for 8-bit images, INTER_LINEAR (OpenCV's two 11-bit fixed-point passes) and INTER_NEAREST; dsize empty =>
+ * (cvRound(cols*fx), cvRound(rows*fy)).  facade/cvlite.cpp */
+void resize(const Mat& src, Mat& dst, Size dsize, double fx = 0, double fy = 0, int interpolation = INTER_LINEAR);
+void rotate(const Mat& src, Mat& dst, int rotateCode);
+inline void circle(Mat&, Point, int, const Scalar&, int = 1, int = 8, int = 0) {}
+inline void line(Mat&, Point, Point, const Scalar&, int = 1, int = 8, int = 0) {}
+inline void rectangle(Mat&, Point, Point, const Scalar&, int = 1, int = 8, int = 0) {}
+inline void rectangle(Mat&, Rect, const Scalar&, int = 1, int = 8, int = 0) {}
+inline void putText(Mat&, const String&, Point, int, double, const Scalar&, int = 1, int = 8, bool = false) {}
+inline void imshow(const String&, const Mat&) {}
+inline int waitKey(int = 0) { return -1; }
 
 /* PNM (P5 / P6) only: enough to feed frames to the demos without libpng. */
 enum { IMREAD_COLOR = 1, IMREAD_GRAYSCALE = 0, IMREAD_UNCHANGED = -1 };

@@ -50,6 +50,10 @@ def lib() -> C.CDLL:
         L.sbo_fast_atan2_deg.restype = f32
         L.sbo_orientation_bins.argtypes = [vp, vp, i64, vp]
         L.sbo_pyrdown.argtypes = [vp, i32, i32, i32, i32, vp]
+        L.sbo_resize_linear_dims.argtypes = [i32, i32, C.c_double, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.sbo_resize_linear_dims.restype = None
+        L.sbo_resize_linear_u8.argtypes = [vp, i32, i32, i32, i32, C.c_double, C.c_double, vp]
+        L.sbo_resize_linear_u8.restype = None
         L.sbo_quantized_orientations.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp, vp]
         L.sbo_spread.argtypes = [vp, i32, i32, i32, vp]
         L.sbo_response_maps.argtypes = [vp, i64, vp]
@@ -129,6 +133,17 @@ def pyrdown(img: np.ndarray) -> np.ndarray:
     shape = (r // 2, c // 2) if img.ndim == 2 else (r // 2, c // 2, ch)
     out = np.empty(shape, np.uint8)
     lib().sbo_pyrdown(_p(img), r, c, ch, c * ch, _p(out))
+    return out
+
+
+def resize_linear(img: np.ndarray, fx: float, fy: float) -> np.ndarray:
+    """cv::resize(img, Size(), fx, fy, INTER_LINEAR) for 8-bit images (shapeInfo_producer::transform)."""
+    img, r, c, ch = _img(img)
+    dr, dc = C.c_int(0), C.c_int(0)
+    lib().sbo_resize_linear_dims(r, c, C.c_double(fx), C.c_double(fy), C.byref(dr), C.byref(dc))
+    shape = (dr.value, dc.value) if img.ndim == 2 else (dr.value, dc.value, ch)
+    out = np.empty(shape, np.uint8)
+    lib().sbo_resize_linear_u8(_p(img), r, c, ch, c * ch, C.c_double(fx), C.c_double(fy), _p(out))
     return out
 
 

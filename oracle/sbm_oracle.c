@@ -137,6 +137,62 @@ void sbo_pyrdown(const uint8_t* src, int rows, int cols, int ch, int stride, uin
 }
 
 /* resize(mask, next, size, 0, 0, INTER_NEAREST).  line2Dup.cpp:439. */
+/* cv::resize(src, dst, Size(), fx, fy, INTER_LINEAR) on 8-bit images, as shapeInfo_producer::transform calls it
+ * (line2Dup.h:383-397).  The arithmetic lives in OpenCV (pinned only as "4", CMakeLists.txt:36); restated from its
+ * published generic path (imgproc/resize.cpp, resizeGeneric_ with HResizeLinear<uchar,int,short> and
+ * VResizeLinear<uchar,int,short>): dsize = (cvRound(cols*fx), cvRound(rows*fy)); per destination coordinate
+ * f = (float)((d + 0.5) / fx - 0.5), s = floor(f), f -= s, clamped to the image; 11-bit coefficients
+ * cvRound((1-f)*2048), cvRound(f*2048); horizontal pass in int, vertical pass
+ * (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.  Unverifiable offline (no OpenCV in the image). */
+static int sbo_cv_round(double v) { return (int)lrint(v); }
+void sbo_resize_linear_dims(int rows, int cols, double fx, double fy, int* drows, int* dcols)
+{
+    *dcols = sbo_cv_round(cols * fx);
+    *drows = sbo_cv_round(rows * fy);
+}
+static void resize_linear_table(int dn, int sn, double scale, int* idx, short* coef)
+{
+    for (int d = 0; d < dn; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= sn - 1) { f = 0.f; s = sn - 1; }
+        idx[d] = s;
+        coef[2 * d] = (short)lrintf((1.f - f) * 2048.f);
+        coef[2 * d + 1] = (short)lrintf(f * 2048.f);
+    }
+}
+void sbo_resize_linear_u8(const uint8_t* src, int rows, int cols, int ch, int stride, double fx, double fy, uint8_t* dst)
+{
+    int drows, dcols;
+    sbo_resize_linear_dims(rows, cols, fx, fy, &drows, &dcols);
+    if (drows <= 0 || dcols <= 0) return;
+    int* xi = (int*)malloc(sizeof(int) * (size_t)dcols);
+    int* yi = (int*)malloc(sizeof(int) * (size_t)drows);
+    short* xa = (short*)malloc(sizeof(short) * 2 * (size_t)dcols);
+    short* ya = (short*)malloc(sizeof(short) * 2 * (size_t)drows);
+    resize_linear_table(dcols, cols, 1.0 / fx, xi, xa);
+    resize_linear_table(drows, rows, 1.0 / fy, yi, ya);
+    for (int y = 0; y < drows; ++y) {
+        const uint8_t* r0 = src + (size_t)yi[y] * stride;
+        const uint8_t* r1 = src + (size_t)(yi[y] + 1 < rows ? yi[y] + 1 : rows - 1) * stride;
+        for (int x = 0; x < dcols; ++x) {
+            const int x0 = xi[x], x1 = x0 + 1 < cols ? x0 + 1 : cols - 1;
+            for (int k = 0; k < ch; ++k) {
+                const int h0 = r0[x0 * ch + k] * xa[2 * x] + r0[x1 * ch + k] * xa[2 * x + 1];
+                const int h1 = r1[x0 * ch + k] * xa[2 * x] + r1[x1 * ch + k] * xa[2 * x + 1];
+                const int v = (((ya[2 * y] * (h0 >> 4)) >> 16) + ((ya[2 * y + 1] * (h1 >> 4)) >> 16) + 2) >> 2;
+                dst[((size_t)y * dcols + x) * ch + k] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+        }
+    }
+    free(xi);
+    free(yi);
+    free(xa);
+    free(ya);
+}
+
 void sbo_resize_nearest_u8(const uint8_t* src, int rows, int cols, uint8_t* dst, int drows, int dcols)
 {
     const double fx = (double)cols / dcols, fy = (double)rows / drows;

@@ -38,6 +38,8 @@ float sbo_fast_atan2_deg(float y, float x);
 void sbo_orientation_bins(const int16_t* dx, const int16_t* dy, int64_t n, uint8_t* q16);
 void sbo_pyrdown(const uint8_t* src, int rows, int cols, int ch, int stride, uint8_t* dst);
 void sbo_resize_nearest_u8(const uint8_t* src, int rows, int cols, uint8_t* dst, int drows, int dcols);
+void sbo_resize_linear_dims(int rows, int cols, double fx, double fy, int* drows, int* dcols);
+void sbo_resize_linear_u8(const uint8_t* src, int rows, int cols, int ch, int stride, double fx, double fy, uint8_t* dst);
 /* quantizedOrientations + hysteresisGradient.  magnitude/angle_ori may be NULL. */
 void sbo_quantized_orientations(const uint8_t* src, int rows, int cols, int ch, int stride,
                                 float weak_threshold, float* magnitude, uint8_t* angle,

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "sbm_level_dims", "sbm_match_templates", "sbm_quantized_orientations", "sbm_pyrdown", "sbm_spread",
     "sbm_compute_response_maps", "sbm_linearize", "sbm_similarity", "sbm_similarity_local",
     "sbm_set_profiling", "sbm_get_timings", "sbm_coarse_bytes", "sbm_get_stats",
-    "sbm_set_result_mirror", "sbm_set_graph_mode", "sbm_set_quantize_mode",
+    "sbm_set_result_mirror", "sbm_set_graph_mode", "sbm_set_quantize_mode", "sbm_resize_linear",
     "sbm_match_templates_device", "sbm_orientation_bins",
     "sbm_comm_unique_id", "sbm_comm_init", "sbm_comm_destroy", "sbm_match_device_sharded", "sbm_match_batch_device_sharded",
 ]
@@ -97,6 +97,7 @@ def lib() -> C.CDLL:
     L.sbm_set_result_mirror.argtypes = [vp, vp, vp]
     L.sbm_set_graph_mode.argtypes = [vp, i32]
     L.sbm_set_quantize_mode.argtypes = [vp, i32, i32]
+    L.sbm_resize_linear.argtypes = [vp, vp, i32, i32, i32, i32, C.c_double, C.c_double, vp, i64, C.POINTER(i32), C.POINTER(i32)]
     L.sbm_match_templates_device.argtypes = [vp, f32, vp, i64, vp, vp]
     L.sbm_comm_unique_id.argtypes = [vp]
     L.sbm_comm_init.argtypes = [vp, i32, i32, vp]
@@ -309,6 +310,15 @@ class Context:
         shape = (r // 2, c // 2) if img.ndim == 2 else (r // 2, c // 2, ch)
         out = np.empty(shape, np.uint8)
         _check(lib().sbm_pyrdown(self._h, _p(img), r, c, c * ch, ch, _p(out)))
+        return out
+
+    def resize_linear(self, img: np.ndarray, fx: float, fy: float) -> np.ndarray:
+        """cv::resize(img, Size(), fx, fy, INTER_LINEAR) of an 8-bit image (shapeInfo_producer::transform)"""
+        a, r, c, ch = _img(img)
+        dr, dc = C.c_int32(0), C.c_int32(0)
+        _check(lib().sbm_resize_linear(self._h, _p(a), r, c, c * ch, ch, fx, fy, None, 0, C.byref(dr), C.byref(dc)))
+        out = np.empty((dr.value, dc.value) if a.ndim == 2 else (dr.value, dc.value, ch), np.uint8)
+        _check(lib().sbm_resize_linear(self._h, _p(a), r, c, c * ch, ch, fx, fy, _p(out), out.size, C.byref(dr), C.byref(dc)))
         return out
 
     def spread(self, q: np.ndarray, T: int) -> np.ndarray:

@@ -1290,6 +1290,52 @@ done:
     return rc;
 }
 
+int sbm_resize_linear(sbm_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t ch, double fx, double fy,
+                      uint8_t* out, int64_t cap_bytes, int32_t* out_rows, int32_t* out_cols)
+{
+    if (!c || !img || rows < 1 || cols < 1 || ch < 1 || ch > 4 || !(fx > 0) || !(fy > 0)) return fail(SBM_ERR_INVALID, "bad argument");
+    if (stride < cols * ch) return fail(SBM_ERR_INVALID, "stride too small");
+    int dr, dc;
+    resize_linear_dims(rows, cols, fx, fy, &dr, &dc);
+    if (out_rows) *out_rows = dr;
+    if (out_cols) *out_cols = dc;
+    if (!out) return 0; // size query
+    if (dr < 1 || dc < 1) return fail(SBM_ERR_INVALID, "resize to an empty image");
+    const size_t nout = (size_t)dr * dc * ch;
+    if ((int64_t)nout > cap_bytes) return fail(SBM_ERR_CAPACITY, "need %zu bytes", nout);
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    std::vector<int32_t> xi, yi;
+    std::vector<int16_t> xa, ya;
+    resize_linear_table(dc, cols, 1.0 / fx, xi, xa);
+    resize_linear_table(dr, rows, 1.0 / fy, yi, ya);
+    DevBuf d_in, d_out, d_xi, d_xa, d_yi, d_ya;
+    int rc = 0;
+    if ((rc = d_in.ensure((size_t)rows * cols * ch)) || (rc = d_out.ensure(nout)) || (rc = d_xi.ensure(xi.size() * 4)) ||
+        (rc = d_xa.ensure(xa.size() * 2)) || (rc = d_yi.ensure(yi.size() * 4)) || (rc = d_ya.ensure(ya.size() * 2)))
+        goto done;
+    if (hipMemcpy2D(d_in.p, (size_t)cols * ch, img, stride, (size_t)cols * ch, rows, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_xi.p, xi.data(), xi.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_xa.p, xa.data(), xa.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_yi.p, yi.data(), yi.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_ya.p, ya.data(), ya.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+        rc = fail(SBM_ERR_HIP, "upload failed");
+        goto done;
+    }
+    hipLaunchKernelGGL(k_resize_linear_u8, dim3((unsigned)std::min<size_t>((nout + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                       d_in.as<uint8_t>(), rows, cols, ch, cols * ch, d_xi.as<int32_t>(), d_xa.as<int16_t>(), d_yi.as<int32_t>(),
+                       d_ya.as<int16_t>(), d_out.as<uint8_t>(), dr, dc);
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, d_out.p, nout, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(SBM_ERR_HIP, "resize failed: %s", hipGetErrorString(hipGetLastError()));
+done:
+    d_in.release();
+    d_out.release();
+    d_xi.release();
+    d_xa.release();
+    d_yi.release();
+    d_ya.release();
+    return rc;
+}
+
 int sbm_spread(sbm_ctx* c, const uint8_t* src, int32_t rows, int32_t cols, int32_t T, uint8_t* dst)
 {
     if (!c || !src || !dst || rows < 1 || cols < 1 || T < 1) return fail(SBM_ERR_INVALID, "bad argument");

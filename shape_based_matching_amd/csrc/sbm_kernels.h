@@ -18,6 +18,7 @@
 #include <stdint.h>
 #include <type_traits>
 #include "../../include/sbm_types.h"
+#include "sbm_resize_table.h"
 
 namespace sbm {
 
@@ -724,6 +725,27 @@ __global__ __launch_bounds__(256) void k_pyrdown(const uint8_t* __restrict__ src
                 dst[(size_t)idx * ch + k] = (uint8_t)((acc + 128) >> 8);
             }
         }
+    }
+}
+
+// cv::resize(INTER_LINEAR) of an 8-bit image with the host-computed coefficient tables (sbm_resize_table.h):
+// one thread per destination sample; training-side helper (shapeInfo_producer::transform, line2Dup.h:379-405)
+__global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restrict__ src, int rows, int cols, int ch, int stride,
+                                                          const int32_t* __restrict__ xi, const int16_t* __restrict__ xa,
+                                                          const int32_t* __restrict__ yi, const int16_t* __restrict__ ya,
+                                                          uint8_t* __restrict__ dst, int drows, int dcols)
+{
+    const int64_t n = (int64_t)drows * dcols * ch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i % ch);
+        const int64_t px = i / ch;
+        const int x = (int)(px % dcols), y = (int)(px / dcols);
+        const int x0 = xi[x], x1 = x0 + 1 < cols ? x0 + 1 : cols - 1;
+        const int y0 = yi[y], y1 = y0 + 1 < rows ? y0 + 1 : rows - 1;
+        const uint8_t* r0 = src + (size_t)y0 * stride;
+        const uint8_t* r1 = src + (size_t)y1 * stride;
+        dst[i] = resize_linear_sample(r0[x0 * ch + k], r0[x1 * ch + k], r1[x0 * ch + k], r1[x1 * ch + k], xa[2 * x], xa[2 * x + 1],
+                                      ya[2 * y], ya[2 * y + 1]);
     }
 }
 

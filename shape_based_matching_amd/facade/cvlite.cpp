@@ -1,5 +1,6 @@
 // cvlite.cpp — implementation of include/sbm_cvlite.h: OpenCV-FileStorage YAML
 // subset (reader + writer) and PNM image I/O.  Host plumbing only.
+#include "../csrc/sbm_resize_table.h"
 #include "../../include/sbm_cvlite.h"
 
 #include <cctype>
@@ -316,6 +317,67 @@ static bool pnm_token(std::istream& f, std::string& tok)
         tok += (char)ch;
     }
     return !tok.empty();
+}
+
+void resize(const Mat& src, Mat& dst, Size dsize, double fx, double fy, int interpolation)
+{
+    CV_Assert(!src.empty() && src.depth() == CV_8U);
+    const int ch = src.channels();
+    int dr, dc;
+    if (dsize.width > 0 && dsize.height > 0) {
+        dc = dsize.width;
+        dr = dsize.height;
+        fx = (double)dc / src.cols;
+        fy = (double)dr / src.rows;
+    } else {
+        CV_Assert(fx > 0 && fy > 0);
+        sbm::resize_linear_dims(src.rows, src.cols, fx, fy, &dr, &dc);
+    }
+    CV_Assert(dr > 0 && dc > 0);
+    Mat out(dr, dc, src.type());
+    if (interpolation == INTER_NEAREST) {
+        for (int y = 0; y < dr; ++y) {
+            const int sy = std::min((int)std::floor(y / fy), src.rows - 1);
+            for (int x = 0; x < dc; ++x) {
+                const int sx = std::min((int)std::floor(x / fx), src.cols - 1);
+                memcpy(out.ptr(y) + (size_t)x * ch, src.ptr(sy) + (size_t)sx * ch, ch);
+            }
+        }
+    } else {
+        CV_Assert(interpolation == INTER_LINEAR);
+        std::vector<int32_t> xi, yi;
+        std::vector<int16_t> xa, ya;
+        sbm::resize_linear_table(dc, src.cols, 1.0 / fx, xi, xa);
+        sbm::resize_linear_table(dr, src.rows, 1.0 / fy, yi, ya);
+        for (int y = 0; y < dr; ++y) {
+            const uchar* r0 = src.ptr(yi[y]);
+            const uchar* r1 = src.ptr(std::min(yi[y] + 1, src.rows - 1));
+            for (int x = 0; x < dc; ++x) {
+                const int x0 = xi[x], x1 = std::min(x0 + 1, src.cols - 1);
+                for (int k = 0; k < ch; ++k)
+                    out.ptr(y)[x * ch + k] = sbm::resize_linear_sample(r0[x0 * ch + k], r0[x1 * ch + k], r1[x0 * ch + k], r1[x1 * ch + k],
+                                                                       xa[2 * x], xa[2 * x + 1], ya[2 * y], ya[2 * y + 1]);
+            }
+        }
+    }
+    dst = out;
+}
+
+void rotate(const Mat& src, Mat& dst, int code)
+{
+    CV_Assert(!src.empty());
+    const size_t es = src.elemSize();
+    const bool swap = code != ROTATE_180;
+    Mat out(swap ? src.cols : src.rows, swap ? src.rows : src.cols, src.type());
+    for (int r = 0; r < src.rows; ++r)
+        for (int c = 0; c < src.cols; ++c) {
+            int rr, cc;
+            if (code == ROTATE_90_CLOCKWISE) { rr = c; cc = src.rows - 1 - r; }
+            else if (code == ROTATE_180) { rr = src.rows - 1 - r; cc = src.cols - 1 - c; }
+            else { rr = src.cols - 1 - c; cc = r; }
+            memcpy(out.ptr(rr) + cc * es, src.ptr(r) + c * es, es);
+        }
+    dst = out;
 }
 
 Mat imread(const std::string& path, int flags)

@@ -6,11 +6,19 @@
 //       addTemplate (angle 0) + addTemplate_rotate for the remaining angles + writeClasses
 //   demo convert <in_fmt> <class_id> <out_fmt>
 //       readClasses + writeClasses (no GPU needed)
+//   demo scale_train <image.ppm> <num_features> <scale_lo> <scale_hi> <scale_step> <templ_fmt> <class_id> <info.yaml>
+//       test.cpp:scale_test("train") (test.cpp:170-203): shapeInfo_producer::src_of / mask_of (cv::resize) + addTemplate
+//   demo nms <templ_fmt> <class_id> <image> <threshold> <num_features> [pad]
+//       test.cpp:noise_test (test.cpp:455-491): match, boxes from templ[0].width/height, NMSBoxes(boxes, scores, 0, 0.5f)
+//   demo instance <config.yaml> <image> <threshold>
+//       Detector::getInstance(path) (line2Dup.cpp:1366-1393) + match over the classes the config lists
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 
 #include "../../include/line2Dup.h"
+#include "../../include/nms.hpp"
 
 using namespace cv;
 
@@ -73,6 +81,84 @@ int main(int argc, char** argv)
             detector.writeClasses(fmt);
             if (argc > 9) shape_based_matching::shapeInfo_producer::save_infos(infos, argv[9]);
             printf("trained %d templates\n", detector.numTemplates());
+            return 0;
+        }
+        if (mode == "scale_train") {
+            if (argc < 10) return usage();
+            Mat img = imread(argv[2], IMREAD_UNCHANGED);
+            if (img.empty()) { fprintf(stderr, "cannot read %s\n", argv[2]); return 1; }
+            const int num_feature = atoi(argv[3]);
+            const std::string fmt = argv[7], class_id = argv[8];
+            line2Dup::Detector detector(num_feature, {4, 8});
+            shape_based_matching::shapeInfo_producer shapes(img);
+            shapes.scale_range = {(float)atof(argv[4]), (float)atof(argv[5])};
+            shapes.scale_step = (float)atof(argv[6]);
+            shapes.produce_infos();
+            std::vector<shape_based_matching::shapeInfo_producer::Info> infos_have_templ;
+            for (auto& info : shapes.infos) {
+                // the call of test.cpp:185-186, argument for argument (in this fork the 4th parameter is `sscale`)
+                int templ_id = detector.addTemplate(shapes.src_of(info), class_id, shapes.mask_of(info), int(num_feature * info.scale));
+                if (templ_id != -1) infos_have_templ.push_back(info);
+            }
+            detector.writeClasses(fmt);
+            shape_based_matching::shapeInfo_producer::save_infos(infos_have_templ, argv[9]);
+            printf("trained %d templates of %zu infos\n", detector.numTemplates(), shapes.infos.size());
+            return 0;
+        }
+        if (mode == "nms") {
+            if (argc < 7) return usage();
+            const std::string fmt = argv[2], class_id = argv[3], path = argv[4];
+            const float threshold = (float)atof(argv[5]);
+            const int num_features = atoi(argv[6]);
+            const int pad = argc > 7 ? atoi(argv[7]) : 0;
+            line2Dup::Detector detector(num_features, {4, 8});
+            std::vector<std::string> ids{class_id};
+            detector.readClasses(ids, fmt);
+            Mat test_img = imread(path, IMREAD_UNCHANGED);
+            if (test_img.empty()) { fprintf(stderr, "cannot read %s\n", path.c_str()); return 1; }
+            Mat padded(test_img.rows + 2 * pad, test_img.cols + 2 * pad, test_img.type(), Scalar::all(0));
+            test_img.copyTo(padded(Rect(pad, pad, test_img.cols, test_img.rows)));
+            const int stride = 16;
+            Mat img = padded(Rect(0, 0, stride * (padded.cols / stride), stride * (padded.rows / stride))).clone();
+            auto matches = detector.match(img, threshold, ids);
+            std::vector<Rect> boxes;
+            std::vector<float> scores;
+            std::vector<int> idxs;
+            for (auto match : matches) { // test.cpp:478-490
+                Rect box;
+                box.x = match.x;
+                box.y = match.y;
+                auto templ = detector.getTemplates(class_id, match.template_id);
+                box.width = templ[0].width;
+                box.height = templ[0].height;
+                boxes.push_back(box);
+                scores.push_back(match.similarity);
+            }
+            cv_dnn::NMSBoxes(boxes, scores, 0, 0.5f, idxs);
+            printf("matches %zu kept %zu\n", matches.size(), idxs.size());
+            for (size_t i = 0; i < matches.size(); ++i) {
+                uint32_t bits;
+                memcpy(&bits, &matches[i].similarity, 4);
+                printf("m %d %d %u %d %d %d\n", matches[i].x, matches[i].y, bits, matches[i].template_id, boxes[i].width, boxes[i].height);
+            }
+            for (int idx : idxs) printf("k %d\n", idx);
+            return 0;
+        }
+        if (mode == "instance") {
+            if (argc < 5) return usage();
+            line2Dup::Detector* det = line2Dup::Detector::getInstance(argv[2]);
+            line2Dup::Detector* again = line2Dup::Detector::getInstance(argv[2]); // the singleton is created once
+            Mat img = imread(argv[3], IMREAD_UNCHANGED);
+            if (img.empty()) { fprintf(stderr, "cannot read %s\n", argv[3]); return 1; }
+            auto matches = det->match(img, (float)atof(argv[4]), det->classIds());
+            printf("instance same %d classes %d templates %d T", det == again ? 1 : 0, det->numClasses(), det->numTemplates());
+            for (int l = 0; l < det->pyramidLevels(); ++l) printf(" %d", det->getT(l));
+            printf(" matches %zu\n", matches.size());
+            for (const auto& m : matches) {
+                uint32_t bits;
+                memcpy(&bits, &m.similarity, 4);
+                printf("%d %d %u %s %d\n", m.x, m.y, bits, m.class_id.c_str(), m.template_id);
+            }
             return 0;
         }
         if (mode == "convert") { // readClasses + writeClasses: exercises the YAML subset without a GPU

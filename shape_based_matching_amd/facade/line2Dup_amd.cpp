@@ -631,27 +631,23 @@ shapeInfo_producer::shapeInfo_producer(cv::Mat src_, cv::Mat mask_)
     mask = mask_.empty() ? cv::Mat(src.size(), CV_8UC1, cv::Scalar(255)) : mask_;
 }
 
+// line2Dup.h:379-405: exactly 90 / 180 / 270 degrees rotate, then resize; every other angle is resize only (the fork
+// removed the warpAffine of upstream and silently ignores such angles)
 cv::Mat shapeInfo_producer::transform(cv::Mat src, float angle, float scale)
 {
-    if (std::abs(scale - 1.0f) > 1e-6f) CV_Error(cv::Error::StsBadArg, "shapeInfo_producer::transform: only scale 1 is supported");
-    float a = std::fmod(angle, 360.f);
-    if (a < 0) a += 360.f;
-    int quarter = -1;
-    for (int q = 0; q < 4; ++q)
-        if (std::abs(a - 90.f * q) < 1e-4f) quarter = q;
-    if (quarter < 0) CV_Error(cv::Error::StsBadArg, "shapeInfo_producer::transform: only multiples of 90 degrees are supported");
-    if (quarter == 0) return src.clone();
-    const size_t es = src.elemSize();
-    const bool swap = quarter != 2;
-    cv::Mat dst(swap ? src.cols : src.rows, swap ? src.rows : src.cols, src.type());
-    for (int r = 0; r < src.rows; ++r)
-        for (int c = 0; c < src.cols; ++c) {
-            int rr, cc;
-            if (quarter == 1) { rr = c; cc = src.rows - 1 - r; }          // ROTATE_90_CLOCKWISE
-            else if (quarter == 2) { rr = src.rows - 1 - r; cc = src.cols - 1 - c; }
-            else { rr = src.cols - 1 - c; cc = r; }                       // ROTATE_90_COUNTERCLOCKWISE
-            memcpy(dst.ptr(rr) + cc * es, src.ptr(r) + c * es, es);
-        }
+    cv::Mat dst;
+    if (std::abs(angle - 90.0) < ANGLE_TOLERANCE) {
+        cv::rotate(src, dst, cv::ROTATE_90_CLOCKWISE);
+        cv::resize(dst, dst, cv::Size(), scale, scale);
+    } else if (std::abs(angle - 180.0) < ANGLE_TOLERANCE) {
+        cv::rotate(src, dst, cv::ROTATE_180);
+        cv::resize(dst, dst, cv::Size(), scale, scale);
+    } else if (std::abs(angle - 270.0) < ANGLE_TOLERANCE) {
+        cv::rotate(src, dst, cv::ROTATE_90_COUNTERCLOCKWISE);
+        cv::resize(dst, dst, cv::Size(), scale, scale);
+    } else {
+        cv::resize(src, dst, cv::Size(), scale, scale);
+    }
     return dst;
 }
 

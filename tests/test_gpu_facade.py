@@ -79,3 +79,119 @@ def test_facade_training_reproduces_reference_fixture(tmp_path, case1):
     assert np.array_equal(got.features, ref.features)
     info = open(str(tmp_path / "info.yaml")).read()
     assert info.count("angle") == 361
+
+
+def _parse_matches(lines):
+    got = [tuple(l.split()) for l in lines]
+    return [(int(a), int(b), int(c), d, int(e)) for a, b, c, d, e in got]
+
+
+def test_facade_scale_train(tmp_path, oracle, golden):
+    """test.cpp:scale_test("train") through the facade: shapeInfo_producer::src_of / mask_of with scale != 1
+    (cv::resize, line2Dup.h:379-405) feeding addTemplate (HIP gradient kernels + host selection), against the
+    oracle's resize + addTemplate"""
+    from shape_based_matching_amd.templates import TemplateSet
+
+    assert os.path.exists(DEMO)
+    img = np.load(os.path.join(golden, "case0_circle_bgr.npz"))["bgr"]
+    write_ppm(str(tmp_path / "circle.ppm"), img)
+    fmt = str(tmp_path / "%s_templ.yaml")
+    r = subprocess.run([DEMO, "scale_train", str(tmp_path / "circle.ppm"), "150", "0.25", "1", "0.25", fmt, "circle",
+                        str(tmp_path / "info.yaml")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = read_class_yaml(fmt % "circle")
+    # produce_infos: for (scale = lo; scale <= hi + eps; scale += step) in float (line2Dup.h:424-428)
+    scales, s = [], np.float32(0.25)
+    while s <= np.float32(1) + np.float32(0.00001):
+        scales.append(s)
+        s = np.float32(s + np.float32(0.25))
+    assert len(scales) == 4
+    t = 0
+    for sc in scales:
+        src = oracle.resize_linear(img, float(sc), float(sc))
+        mask = np.full(src.shape[:2], 255, np.uint8)
+        res = oracle.add_template(src, mask, 2, 150)  # the fork's addTemplate: 4th argument is sscale, the count stays 150
+        if res is None:
+            continue
+        levels, feats = res
+        for l in range(2):
+            lv, ref = levels[l], got.levels[t, l]
+            for k in ("width", "height", "tl_x", "tl_y", "n_features"):
+                assert int(lv[k]) == int(ref[k]), (float(sc), l, k)
+            mine = feats[int(lv["feature_offset"]): int(lv["feature_offset"]) + int(lv["n_features"])]
+            rf = got.feats_of(t, l)
+            assert np.array_equal(mine["x"], rf["x"]) and np.array_equal(mine["y"], rf["y"]) and np.array_equal(mine["label"], rf["label"])
+        t += 1
+    assert t == got.n_templates and t >= 3
+    assert open(str(tmp_path / "info.yaml")).read().count("scale") == t
+
+
+def test_facade_nms_flow_case2(tmp_path, oracle, case2):
+    """test.cpp:noise_test (455-491): Detector(30, {4,8}) -> match(img, 90) -> boxes from templ[0] -> NMSBoxes(0, 0.5)"""
+    from test_nms import py_nms
+
+    assert os.path.exists(DEMO)
+    ts = case2["templates"]
+    fmt = str(tmp_path / "%s_templ.yaml")
+    write_class_yaml(ts, fmt % "test")
+    img = case2["test"]
+    write_ppm(str(tmp_path / "test.ppm"), img)
+    r = subprocess.run([DEMO, "nms", fmt, "test", str(tmp_path / "test.ppm"), "90", "30", "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    ms = [tuple(int(v) for v in l.split()[1:]) for l in lines if l.startswith("m ")]
+    kept = [int(l.split()[1]) for l in lines if l.startswith("k ")]
+    assert len(ms) > 0 and lines[0] == f"matches {len(ms)} kept {len(kept)}"
+    # the match list itself: oracle, canonical order, the reference's adjacent unique
+    frame = np.ascontiguousarray(img[: img.shape[0] // 16 * 16, : img.shape[1] // 16 * 16])
+    pyr = oracle.Pyramid.build(frame, [4, 8], 30.0)
+    want = oracle.canonicalize(pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 90.0))
+    keep = []
+    for m in want:
+        k = (int(m["x"]), int(m["y"]), int(m["similarity"].view(np.uint32)))
+        if keep and keep[-1][:3] == k:
+            continue
+        keep.append(k + (int(m["template_id"]),))
+    assert [m[:4] for m in ms] == keep
+    # boxes are (x, y, width, height of level 0 of the matched template), scores the similarities
+    for m in ms:
+        assert (m[4], m[5]) == (int(ts.levels[m[3], 0]["width"]), int(ts.levels[m[3], 0]["height"]))
+    boxes = [[m[0], m[1], m[4], m[5]] for m in ms]
+    scores = [float(np.uint32(m[2]).view(np.float32)) for m in ms]
+    assert kept == py_nms(boxes, scores, 0.0, 0.5)
+    assert 0 < len(kept) < len(ms)
+
+
+def test_facade_get_instance(tmp_path, case1):
+    """Detector::getInstance(path) (line2Dup.cpp:1366-1393): detector settings + `classes` + `templates_dir` from one
+    YAML, templates from <dir>/<class>.yaml.gz; the singleton is built once; matches equal the explicit flow's"""
+    import gzip
+
+    assert os.path.exists(DEMO)
+    ts = case1["templates"].subset(range(300, 361, 2))
+    ts.template_id[:] = np.arange(ts.n_templates)  # readClass asserts template_id == index (:1532)
+    tdir = tmp_path / "templates"
+    tdir.mkdir()
+    plain = str(tmp_path / "test_plain.yaml")
+    write_class_yaml(ts, plain)
+    with open(plain, "rb") as f, gzip.open(str(tdir / "test.yaml.gz"), "wb") as g:
+        g.write(f.read())
+    cfg = str(tmp_path / "detector_linemod.yaml")
+    with open(cfg, "w") as f:
+        f.write("%YAML:1.0\n---\npyramid_levels: 2\nT: [ 4, 8 ]\ntype: ColorGradient\nweak_threshold: 30.\nnum_features: 128\n"
+                f"strong_threshold: 60.\ntemplates_dir: \"{tdir}\"\nclasses:\n   - \"test\"\n")
+    frame = synth.embed(case1["test"], 640, 768, 80, 80)
+    write_ppm(str(tmp_path / "frame.ppm"), frame)
+    r = subprocess.run([DEMO, "instance", cfg, str(tmp_path / "frame.ppm"), "88"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    head = [l for l in lines if l.startswith("instance ")][0]
+    assert head.startswith(f"instance same 1 classes 1 templates {ts.n_templates} T 4 8 matches ")
+    got = _parse_matches(lines[lines.index(head) + 1:])
+    fmt = str(tmp_path / "%s_plain.yaml")
+    r2 = subprocess.run([DEMO, "match", fmt, "test", str(tmp_path / "frame.ppm"), "88", "128", "0"], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr
+    assert got == _parse_matches(r2.stdout.strip().splitlines()[1:]) and len(got) > 0
+    # a missing configuration file throws (line2Dup.cpp:1369-1373)
+    r3 = subprocess.run([DEMO, "instance", str(tmp_path / "nope.yaml"), str(tmp_path / "frame.ppm"), "88"], capture_output=True, text=True)
+    assert r3.returncode != 0

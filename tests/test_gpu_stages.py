@@ -198,3 +198,19 @@ def test_orientation_bins_exhaustive(oracle, ctx_factory):
     got = ctx.orientation_bins(gx.ravel(), gy.ravel())
     assert np.array_equal(got, want)
     assert set(np.unique(want)) == set(range(17))
+
+
+def test_resize_linear(oracle, ctx_factory):
+    """sbm_resize_linear = cv::resize(INTER_LINEAR) of shapeInfo_producer::transform (line2Dup.h:379-405)"""
+    rs = np.random.RandomState(21)
+    ctx = ctx_factory()
+    for shape in ((37, 53, 3), (64, 64), (5, 9, 3), (300, 150), (270, 270, 3)):
+        img = rs.randint(0, 256, shape).astype(np.uint8)
+        for fx, fy in ((0.1, 0.1), (0.37, 0.37), (0.5, 0.5), (0.99999934, 0.99999934), (1.0, 1.0), (1.7, 1.7), (2.0, 0.5)):
+            want = oracle.resize_linear(img, fx, fy)
+            if want.size == 0:  # cvRound(rows * fy) == 0: cv::resize asserts, the engine reports an error
+                with pytest.raises(Exception):
+                    ctx.resize_linear(img, fx, fy)
+                continue
+            got = ctx.resize_linear(img, fx, fy)
+            assert got.shape == want.shape and np.array_equal(got, want), (shape, fx, fy)

@@ -135,3 +135,69 @@ def test_integer_orientation_rule_equals_float_pipeline(oracle):
     k = np.where(gx < 0, 8 - k, k)
     k = np.where(gy < 0, 16 - k, k)
     assert np.array_equal(k, oracle.orientation_bins(gx.astype(np.int16), gy.astype(np.int16)).astype(np.int64))
+
+
+# ---- cv::resize (shapeInfo_producer::transform, line2Dup.h:379-405) and the case0 fixture --------------------------
+def _resize_linear_numpy(src, fx, fy):
+    """independent restatement of OpenCV's 8-bit INTER_LINEAR resize (two 11-bit fixed-point passes)"""
+    src = np.ascontiguousarray(src)
+    sh, sw = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    s3 = src.reshape(sh, sw, cn).astype(np.int64)
+    dw, dh = int(np.rint(sw * float(fx))), int(np.rint(sh * float(fy)))
+
+    def tab(dn, sn, scale):
+        idx = np.zeros(dn, np.int64)
+        a0 = np.zeros(dn, np.int64)
+        a1 = np.zeros(dn, np.int64)
+        for d in range(dn):
+            f = np.float32((d + 0.5) * scale - 0.5)
+            s = int(np.floor(f))
+            f = np.float32(f - np.float32(s))
+            if s < 0:
+                f, s = np.float32(0), 0
+            if s >= sn - 1:
+                f, s = np.float32(0), sn - 1
+            idx[d] = s
+            a0[d] = int(np.rint(np.float32(np.float32(1.0) - f) * np.float32(2048)))
+            a1[d] = int(np.rint(f * np.float32(2048)))
+        return idx, a0, a1
+
+    xi, xa0, xa1 = tab(dw, sw, 1.0 / float(fx))
+    yi, ya0, ya1 = tab(dh, sh, 1.0 / float(fy))
+    H = s3[:, xi, :] * xa0[None, :, None] + s3[:, np.minimum(xi + 1, sw - 1), :] * xa1[None, :, None]
+    S0, S1 = H[yi], H[np.minimum(yi + 1, sh - 1)]
+    out = (((ya0[:, None, None] * (S0 >> 4)) >> 16) + ((ya1[:, None, None] * (S1 >> 4)) >> 16) + 2) >> 2
+    out = np.clip(out, 0, 255).astype(np.uint8)
+    return out.reshape(dh, dw) if src.ndim == 2 else out
+
+
+def test_resize_linear_against_numpy_restatement(oracle):
+    rs = np.random.RandomState(11)
+    for shape in ((37, 53, 3), (64, 64), (5, 9, 3), (200, 150)):
+        img = rs.randint(0, 256, shape).astype(np.uint8)
+        assert np.array_equal(oracle.resize_linear(img, 1.0, 1.0), img)  # scale 1 is the identity
+        for fx in (0.1, 0.37, 0.5, 0.99999934, 1.7, 2.0):
+            a, b = oracle.resize_linear(img, fx, fx), _resize_linear_numpy(img, fx, fx)
+            assert a.shape == b.shape and np.array_equal(a, b), (shape, fx)
+
+
+def test_case0_fixture_was_not_made_by_this_fork():
+    """test/case0/circle_templ.yaml cannot be re-derived from case0/templ/circle.png with this fork's code (the way
+    test/case1/test_templ.yaml is, above), for two reasons the file itself shows:
+    1. geometry: every template sits around the centre of the 800 x 800 training canvas whatever its scale (tl + half the
+       box = 400 +- 2) -- upstream's transform() warped the image in place with getRotationMatrix2D/warpAffine; this fork
+       removed that (line2Dup.h:396-403) and cv::resize's the whole image instead, which moves the object to (400 * scale);
+    2. counts: level 0 holds exactly int(150 * scale) features for every scale -- the signature of upstream's older
+       selectScatteredFeatures; the fork's version (line2Dup.cpp:163-212) over- or under-shoots (131 / 71 for 128 / 64 in
+       case1) and its addTemplate takes the 4th argument as `sscale`, not as the feature count (line2Dup.h:276-286).
+    The file therefore stays an INPUT fixture (template data for the matcher), like case2."""
+    from shape_based_matching_amd.templates import TemplateSet
+
+    ts = TemplateSet.load_npz(os.path.join(GOLDEN, "case0_templates.npz"))
+    scales = np.load(os.path.join(GOLDEN, "case0_info_scales.npy"))
+    assert ts.n_templates == len(scales) == 89
+    for t in range(ts.n_templates):
+        lv = ts.levels[t, 0]
+        assert int(lv["n_features"]) == int(np.float32(150) * scales[t]), t
+        assert abs(int(lv["tl_x"]) + int(lv["width"]) / 2 - 400) <= 2 and abs(int(lv["tl_y"]) + int(lv["height"]) / 2 - 400) <= 2, t

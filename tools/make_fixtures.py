@@ -7,6 +7,8 @@ Every output is DATA held by the reference's tests, re-encoded compactly:
   case1_train_bgr.npz        <- test/case1/train.png  (BGR pixels as cv::imread would return)
   case1_test_bgr.npz         <- test/case1/test.png
   case2_train_bgr.npz, case2_test_bgr.npz
+  case0_circle_bgr.npz       <- test/case0/templ/circle.png (the training image of test.cpp:scale_test)
+  case0_info_scales.npy      <- the `scale:` values of test/case0/circle_info.yaml (float32)
   similarity_lut.sha256      <- digest of the 256 SIMILARITY_LUT entries (line2Dup.cpp:635)
 No reference source text is copied.
 """
@@ -50,6 +52,11 @@ def main():
         a = imread_bgr(f"{REF}/test/case{case}/{which}.png")
         np.savez_compressed(f"{OUT}/case{case}_{which}_bgr.npz", bgr=a)
         print(f"case{case}_{which}: {a.shape}")
+    a = imread_bgr(f"{REF}/test/case0/templ/circle.png")
+    np.savez_compressed(f"{OUT}/case0_circle_bgr.npz", bgr=a)
+    scales = [float(x) for x in re.findall(r"scale: ([0-9.e+-]+)", open(f"{REF}/test/case0/circle_info.yaml").read())]
+    np.save(f"{OUT}/case0_info_scales.npy", np.asarray(scales, np.float32))
+    print(f"case0 circle: {a.shape}, {len(scales)} infos")
     lut = parse_similarity_lut(f"{REF}/line2Dup.cpp")
     with open(f"{OUT}/similarity_lut.sha256", "w") as fh:
         fh.write(hashlib.sha256(lut.tobytes()).hexdigest() + "\n")
