@@ -232,6 +232,9 @@ private:
     mutable sbm_ctx* ctx_;
     mutable bool templates_dirty_;
     mutable std::vector<std::string> uploaded_class_order_;
+    mutable std::vector<int32_t> selected_;   /* class selection currently active in the engine (match() caches it) */
+    mutable bool selection_valid_ = false;
+    mutable std::vector<unsigned char> recs_;  /* match record scratch, kept between calls */
     int device_id_;
     void ensureContext() const;
     void uploadTemplates() const;

@@ -129,6 +129,21 @@ struct sbm_ctx {
     int comm_world = 0, comm_rank = 0;
     sbm_match_rec* mirror_out = nullptr; // optional device-visible mirror of the results (sbm_set_result_mirror)
     int32_t* mirror_count = nullptr;
+    // host entry point (sbm_match): pinned result buffer the last kernel writes into (no device-to-host copy, one
+    // synchronisation per call) and a small cache of caller frame buffers pinned with hipHostRegister, so that the
+    // frame upload of a caller that re-uses its buffer (a camera loop) is one asynchronous DMA instead of a staged
+    // pageable copy
+    sbm_match_rec* h_res = nullptr;
+    int32_t* h_res_count = nullptr;
+    int64_t h_res_cap = 0;
+    struct PinnedFrame {
+        const void* p = nullptr;
+        size_t bytes = 0;
+        int seen = 0;
+        bool registered = false;
+        uint64_t last_use = 0;
+    } pinned[4];
+    uint64_t pin_clock = 0;
     DevBuf d_scratch;
 
     // hipGraph cache for sbm_match_device (one captured graph per distinct argument tuple)
@@ -851,6 +866,10 @@ void sbm_destroy(sbm_ctx* c)
     (void)hipSetDevice(c->cfg.device_id);
     (void)hipDeviceSynchronize();
     if (c->comm && g_rccl_destroy_hook) g_rccl_destroy_hook(c);
+    for (auto& pf : c->pinned)
+        if (pf.registered) (void)hipHostUnregister((void*)pf.p);
+    if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->h_res_count) (void)hipHostFree(c->h_res_count);
     c->drop_graphs();
     for (int l = 0; l < SBM_MAX_LEVELS; ++l)
         if (c->ev_fork[l]) (void)hipEventDestroy(c->ev_fork[l]);
@@ -1095,6 +1114,27 @@ static int upload_image(sbm_ctx* c, const uint8_t* img, int rows, int cols, int 
     if (!img) return fail(SBM_ERR_INVALID, "null image");
     if (stride < cols * ch) return fail(SBM_ERR_INVALID, "stride %d < cols*channels", stride);
     if (int e = ensure_geometry(c, rows, cols, ch)) return e;
+    { // pin a frame buffer the caller keeps handing in (second sighting): the copy below then is a plain DMA
+        const size_t bytes = (size_t)stride * (rows - 1) + (size_t)cols * ch;
+        sbm_ctx::PinnedFrame* hit = nullptr;
+        sbm_ctx::PinnedFrame* lru = &c->pinned[0];
+        for (auto& pf : c->pinned) {
+            if (pf.p == img && pf.bytes == bytes) hit = &pf;
+            if (pf.last_use < lru->last_use) lru = &pf;
+        }
+        if (!hit) {
+            if (lru->registered) (void)hipHostUnregister((void*)lru->p);
+            *lru = sbm_ctx::PinnedFrame();
+            lru->p = img;
+            lru->bytes = bytes;
+            hit = lru;
+        }
+        hit->last_use = ++c->pin_clock;
+        if (!hit->registered && ++hit->seen == 2 && bytes >= (1u << 16)) {
+            if (hipHostRegister((void*)img, bytes, hipHostRegisterDefault) == hipSuccess) hit->registered = true;
+            else (void)hipGetLastError(); // not pinnable (e.g. read-only mapping): keep the pageable path
+        }
+    }
     HIP_TRY(hipMemcpy2DAsync(c->d_img[0].p, (size_t)cols * ch, img, stride, (size_t)cols * ch, rows, hipMemcpyHostToDevice, c->stream));
     if (mask) HIP_TRY(hipMemcpyAsync(c->d_mask[0].p, mask, (size_t)rows * cols, hipMemcpyHostToDevice, c->stream));
     return 0;
@@ -1111,9 +1151,53 @@ int sbm_match(sbm_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_
     if (int e = enqueue_pyramid(c, c->stream, c->d_img[0].as<uint8_t>(), cols * channels, mask ? c->d_mask[0].as<uint8_t>() : nullptr,
                                 c->d_outcount.as<int32_t>()))
         return e;
-    if (int e = enqueue_coarse(c, c->stream, c->d_out.as<sbm_match_rec>(), c->cand_cap, c->d_outcount.as<int32_t>())) return e;
-    if (int e = enqueue_local(c, c->stream, c->d_out.as<sbm_match_rec>(), c->cand_cap, c->d_outcount.as<int32_t>())) return e;
-    int rc = fetch_results(c, c->stream, out, cap, n_out);
+    // results: the emitting kernel also stores every record and the final {count, overflow} pair into pinned host
+    // memory, so one stream synchronisation ends the call; lists longer than the pinned buffer take the copy path
+    sbm_match_rec* const user_mo = c->mirror_out;
+    int32_t* const user_mc = c->mirror_count;
+    bool own_mirror = false;
+    if (!user_mo) {
+        if (!c->h_res) {
+            c->h_res_cap = 4096;
+            if (hipHostMalloc((void**)&c->h_res, (size_t)c->h_res_cap * sizeof(sbm_match_rec), hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc((void**)&c->h_res_count, 16, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                if (c->h_res) (void)hipHostFree(c->h_res);
+                c->h_res = nullptr;
+                c->h_res_count = nullptr;
+            }
+        }
+        if (c->h_res && c->h_res_count) {
+            c->h_res_count[0] = -1;
+            c->h_res_count[1] = 0;
+            c->mirror_out = c->h_res;
+            c->mirror_count = c->h_res_count;
+            own_mirror = true;
+        }
+    }
+    // with the pinned mirror the emitting kernel's record capacity is the pinned buffer's (it bounds both copies)
+    const int64_t dev_cap = own_mirror ? std::min<int64_t>(c->cand_cap, c->h_res_cap) : c->cand_cap;
+    int rc = enqueue_coarse(c, c->stream, c->d_out.as<sbm_match_rec>(), dev_cap, c->d_outcount.as<int32_t>());
+    if (!rc) rc = enqueue_local(c, c->stream, c->d_out.as<sbm_match_rec>(), dev_cap, c->d_outcount.as<int32_t>());
+    c->mirror_out = user_mo;
+    c->mirror_count = user_mc;
+    if (rc) return rc;
+    if (own_mirror) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const int n = c->h_res_count[0];
+        if (n >= 0 && c->h_res_count[1] == 0 && n <= dev_cap) {
+            *n_out = n;
+            if (n > cap) return fail(SBM_ERR_CAPACITY, "%d matches exceed the output capacity %lld", n, (long long)cap);
+            if (n > 0) memcpy(out, c->h_res, (size_t)n * sizeof(sbm_match_rec));
+            if (c->profiling) collect_timings(c);
+            return 0;
+        }
+        // more records than the pinned buffer holds (or a candidate overflow to report): run the template loop again on
+        // the resident pyramid with the full device capacity and take the copy path
+        if ((rc = enqueue_coarse(c, c->stream, c->d_out.as<sbm_match_rec>(), c->cand_cap, c->d_outcount.as<int32_t>()))) return rc;
+        if ((rc = enqueue_local(c, c->stream, c->d_out.as<sbm_match_rec>(), c->cand_cap, c->d_outcount.as<int32_t>()))) return rc;
+    }
+    rc = fetch_results(c, c->stream, out, cap, n_out);
     if (c->profiling) collect_timings(c);
     return rc;
 }

@@ -10,8 +10,11 @@
 //       test.cpp:scale_test("train") (test.cpp:170-203): shapeInfo_producer::src_of / mask_of (cv::resize) + addTemplate
 //   demo nms <templ_fmt> <class_id> <image> <threshold> <num_features> [pad]
 //       test.cpp:noise_test (test.cpp:455-491): match, boxes from templ[0].width/height, NMSBoxes(boxes, scores, 0, 0.5f)
+//   demo latency <templ_fmt> <class_id> <image> <threshold> <num_features> <n> [pad]
+//       n timed calls of detector.match(img, threshold, ids) on one cv::Mat, as a test.cpp-style caller sees them
 //   demo instance <config.yaml> <image> <threshold>
 //       Detector::getInstance(path) (line2Dup.cpp:1366-1393) + match over the classes the config lists
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -142,6 +145,30 @@ int main(int argc, char** argv)
                 printf("m %d %d %u %d %d %d\n", matches[i].x, matches[i].y, bits, matches[i].template_id, boxes[i].width, boxes[i].height);
             }
             for (int idx : idxs) printf("k %d\n", idx);
+            return 0;
+        }
+        if (mode == "latency") {
+            if (argc < 8) return usage();
+            const std::string fmt = argv[2], class_id = argv[3], path = argv[4];
+            const float threshold = (float)atof(argv[5]);
+            const int num_features = atoi(argv[6]), n = atoi(argv[7]);
+            const int pad = argc > 8 ? atoi(argv[8]) : 0;
+            line2Dup::Detector detector(num_features, {4, 8});
+            std::vector<std::string> ids{class_id};
+            detector.readClasses(ids, fmt);
+            Mat test_img = imread(path, IMREAD_UNCHANGED);
+            if (test_img.empty()) { fprintf(stderr, "cannot read %s\n", path.c_str()); return 1; }
+            Mat padded(test_img.rows + 2 * pad, test_img.cols + 2 * pad, test_img.type(), Scalar::all(0));
+            test_img.copyTo(padded(Rect(pad, pad, test_img.cols, test_img.rows)));
+            const int stride = 16;
+            Mat img = padded(Rect(0, 0, stride * (padded.cols / stride), stride * (padded.rows / stride))).clone();
+            size_t n_matches = 0;
+            for (int i = 0; i < 10; ++i) n_matches = detector.match(img, threshold, ids).size();
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < n; ++i) n_matches = detector.match(img, threshold, ids).size();
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / n;
+            printf("latency %.1f us per Detector::match, image %dx%dx%d, %d templates, %zu matches\n", us, img.rows, img.cols,
+                   img.channels(), detector.numTemplates(), n_matches);
             return 0;
         }
         if (mode == "instance") {

@@ -320,6 +320,7 @@ Detector::~Detector() { dropContext(); }
 
 void Detector::dropContext()
 {
+    selection_valid_ = false;
     if (ctx_) sbm_destroy(ctx_);
     ctx_ = nullptr;
     templates_dirty_ = true;
@@ -353,6 +354,7 @@ void Detector::uploadTemplates() const
     std::vector<sbm_feature> feats;
     std::vector<int32_t> cls, tid;
     uploaded_class_order_.clear();
+    selection_valid_ = false; // sbm_upload_templates selects every class again
     for (const auto& kv : class_templates) {
         const int ci = (int)uploaded_class_order_.size();
         uploaded_class_order_.push_back(kv.first);
@@ -398,20 +400,25 @@ std::vector<Match> Detector::match(Mat source, float threshold, const std::vecto
         }
         if (sel.empty()) return matches;
     }
-    check(sbm_select_classes(ctx_, sel.empty() ? nullptr : sel.data(), (int32_t)sel.size()), "sbm_select_classes");
+    if (!selection_valid_ || sel != selected_) { // the selection call synchronises the device: only when it changes
+        check(sbm_select_classes(ctx_, sel.empty() ? nullptr : sel.data(), (int32_t)sel.size()), "sbm_select_classes");
+        selected_ = sel;
+        selection_valid_ = true;
+    }
 
     Mat mask8;
     if (!mask.empty()) {
         CV_Assert(mask.type() == CV_8UC1);
         mask8 = mask.isContinuous() ? mask : mask.clone();
     }
-    std::vector<sbm_match_rec> recs(1 << 16);
+    if (recs_.size() < (size_t)4096 * sizeof(sbm_match_rec)) recs_.resize((size_t)4096 * sizeof(sbm_match_rec));
     int64_t n = 0;
     for (;;) {
+        const int64_t cap = (int64_t)(recs_.size() / sizeof(sbm_match_rec));
         int rc = sbm_match(ctx_, source.data, source.rows, source.cols, (int)source.step, source.channels(),
-                           mask8.empty() ? nullptr : mask8.data, threshold, recs.data(), (int64_t)recs.size(), &n);
-        if (rc == SBM_ERR_CAPACITY && n > (int64_t)recs.size()) {
-            recs.resize((size_t)n);
+                           mask8.empty() ? nullptr : mask8.data, threshold, (sbm_match_rec*)recs_.data(), cap, &n);
+        if (rc == SBM_ERR_CAPACITY && n > cap) {
+            recs_.resize((size_t)n * sizeof(sbm_match_rec));
             continue;
         }
         check(rc, "sbm_match");
@@ -419,7 +426,8 @@ std::vector<Match> Detector::match(Mat source, float threshold, const std::vecto
     }
     // epilogue (:1142-1145): canonical sort, exact-duplicate removal, then the reference's own
     // adjacent std::unique (its operator== ignores template_id)
-    n = sbm_canonicalize(recs.data(), n);
+    sbm_match_rec* recs = (sbm_match_rec*)recs_.data();
+    n = sbm_canonicalize(recs, n);
     matches.reserve((size_t)n);
     for (int64_t i = 0; i < n; ++i)
         matches.push_back(Match(recs[i].x, recs[i].y, recs[i].similarity, uploaded_class_order_[recs[i].class_idx], recs[i].template_id));

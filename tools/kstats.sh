@@ -2,7 +2,7 @@
 # usage: [KS_ARGS="--frame tiled"] tools/kstats.sh <label>  — rocprofv3 kernel-trace of a short single-stream bench run; per (kernel, grid) mean durations
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/ks_$1
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/ks_$1 -o ks -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --inflight 1 $KS_ARGS > $GRAFT_REPO_ROOT/gpurun_out/ks_$1.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/ks_$1 -o ks -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra-frames --inflight 1 $KS_ARGS > $GRAFT_REPO_ROOT/gpurun_out/ks_$1.log 2>&1
 python3 - <<PY
 import csv, collections
 rows = list(csv.DictReader(open("$GRAFT_REPO_ROOT/gpurun_out/ks_$1/ks_kernel_trace.csv")))

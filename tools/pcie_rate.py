@@ -9,7 +9,7 @@ import bench
 from shape_based_matching_amd import capi
 from shape_based_matching_amd.templates import MATCH_DTYPE
 
-ts, frame = bench.load_workload(1)
+ts, frame = bench.case1_templates(360), bench.case1_frame("case1", 1024, 1024)
 dev = torch.device("cuda", 0)
 R, C = frame.shape[:2]
 ctx = capi.Context(T=bench.T_LEVELS, weak_threshold=30.0, device_id=0)
