@@ -260,10 +260,10 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
                                 nve = select(pyr_last, ve >> 16, nve);
                             }
                             const V m2 = alignbit(ve, pve, 16), m1 = alignbit(vo, pvo, 16), p2 = alignbit(nve, ve, 16);
-                            V s = pk_add(m2, p2);
-                            s = pk_mad(pk_add(m1, vo), K4, s);
+                            V s = m2 + p2; // halves stay below 2^16 (<= 65408 in total): plain 32-bit adds
+                            s = pk_mad(m1 + vo, K4, s);
                             s = pk_mad(ve, QS_K(6, 6), s);
-                            ob[c] = pk_lshr(pk_add(s, QS_K(128, 128)), 8);
+                            ob[c] = pk_lshr(s + QS_K(128, 128), 8);
                         }
                     }
                     if (CH == 3) {
@@ -309,9 +309,11 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
                     V g[2]; // vertical pass: (g0, g2), (g1, g3), <= 65280
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const V s06 = pk_add(st.win[(k + 1) % 7][c][h], st.win[k][c][h]);
-                        const V s15 = pk_add(st.win[(k + 2) % 7][c][h], st.win[(k + 6) % 7][c][h]);
-                        const V s24 = pk_add(st.win[(k + 3) % 7][c][h], st.win[(k + 5) % 7][c][h]);
+                        // sums of two bytes per 16-bit half: no carry between the halves, so the full-rate 32-bit add does
+                        // (v_add_u32 issues every 2 cycles, the packed 16-bit forms every 4)
+                        const V s06 = st.win[(k + 1) % 7][c][h] + st.win[k][c][h];
+                        const V s15 = st.win[(k + 2) % 7][c][h] + st.win[(k + 6) % 7][c][h];
+                        const V s24 = st.win[(k + 3) % 7][c][h] + st.win[(k + 5) % 7][c][h];
                         V acc = pk_mul(st.win[(k + 4) % 7][c][h], QS_K(72, 72));
                         acc = pk_mad(s24, QS_K(56, 56), acc);
                         acc = pk_mad(s15, QS_K(28, 28), acc);
@@ -344,9 +346,9 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
                     const V LE = alignbit(SO, pSO, 16); // (s-1, s1)
                     const V RO = alignbit(nSE, SE, 16); // (s2, s4)
                     dxc[c][0] = pk_sub(SO, LE);
-                    sxc[c][0] = pk_add(pk_mad(SE, K2, LE), SO);
+                    sxc[c][0] = pk_mad(SE, K2, LE) + SO; // <= 1020 per half: plain 32-bit add
                     dxc[c][1] = pk_sub(RO, SE);
-                    sxc[c][1] = pk_add(pk_mad(SO, K2, SE), RO);
+                    sxc[c][1] = pk_mad(SO, K2, SE) + RO;
                 }
             } else { // never read by a row that is stored (see the stage gating above)
 #pragma unroll
