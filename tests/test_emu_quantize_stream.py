@@ -109,3 +109,16 @@ def test_extreme_gradients(emu, oracle):
     e[::2, :] = 255
     check(emu, oracle, e)
     check(emu, oracle, (np.indices((64, 64)).sum(0) % 2 * 255).astype(np.uint8))
+
+
+@pytest.mark.parametrize("ch", [1, 3])
+def test_constant_run_fast_forward_chunks(emu, oracle, ch):
+    """long constant runs are consumed seven rows at a time; a textured band starting at every phase of that chunking
+    must end the run on the right row"""
+    rs = np.random.RandomState(5)
+    for start in range(40, 54):
+        img = np.full((140, 256) + ((3,) if ch == 3 else ()), 90, np.uint8)
+        img[start:start + 9] = rs.randint(0, 256, (9,) + img.shape[1:])
+        img[120:] = 200  # a second colour: a new run after one changing row
+        for hs in (32, 64, 140):
+            check(emu, oracle, img, hs=hs)

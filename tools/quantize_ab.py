@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--mixed", action="store_true", help="frames that are partly constant (balance of the work items)")
     args = ap.parse_args()
     import torch
     from shape_based_matching_amd import capi
@@ -27,7 +28,14 @@ def main():
         tex = np.ascontiguousarray(np.tile(img, reps)[:rows, :cols])
         if ch == 1:
             tex = np.ascontiguousarray(tex[:, :, 1])
-        for kind, frame in (("textured", tex), ("constant", np.full_like(tex, 40))):
+        half = tex.copy()
+        half[rows // 2:] = 40
+        emb = np.zeros_like(tex)
+        ih, iw = min(img.shape[0], rows), min(img.shape[1], cols)
+        sub = img[:ih, :iw] if ch == 3 else img[:ih, :iw, 1]
+        emb[(rows - ih) // 2:(rows - ih) // 2 + ih, (cols - iw) // 2:(cols - iw) // 2 + iw] = sub
+        kinds = (("textured", tex), ("constant", np.full_like(tex, 40))) if not args.mixed else (("half", half), ("embedded", emb))
+        for kind, frame in kinds:
             d_img = torch.from_numpy(np.stack([frame] * B)).to(dev)
             cap = 4096
             d_out = torch.zeros(B * cap * MATCH_DTYPE.itemsize, dtype=torch.uint8, device=dev)
