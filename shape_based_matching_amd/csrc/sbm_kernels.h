@@ -1202,8 +1202,11 @@ __device__ __forceinline__ void accumulate_features_strip(const uint8_t* __restr
                 pr[k] = (uint32_t)__builtin_amdgcn_readlane((int)rec, (u + k) & 63);
                 const uint8_t* p = lmc + ((size_t)(pr[k] >> 7) << 4) + ((pr[k] & 3u) << 2); // + q dwords
                 const uint32_t t = (pr[k] & 3u) + lq;                                      // dword index a = q + lq in 0 .. 6
-                d0[k] = *(const uint32_t*)(p + (p0 + (t >> 2) * wrap));
-                d1[k] = *(const uint32_t*)(p + (p0 + ((t + 1) >> 2) * wrap) + 4);
+                // 32-bit offsets (v_mad_u32_u24: the 64-bit multiply-add the pointer arithmetic would otherwise become
+                // issues at a quarter of the rate)
+                const uint32_t off0 = __umul24(t >> 2, wrap) + p0, off1 = __umul24((t + 1) >> 2, wrap) + p0;
+                d0[k] = *(const uint32_t*)(p + off0);
+                d1[k] = *(const uint32_t*)(p + off1 + 4);
             }
 #pragma unroll
             for (int k = 0; k < n; ++k)
