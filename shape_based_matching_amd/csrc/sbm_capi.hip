@@ -157,6 +157,8 @@ struct sbm_ctx {
         void* count;
         void* mo;
         void* mc;
+        int frames;       // 0: single-frame graph (sbm_match_device), else the batch size
+        int64_t frame_stride;
         hipGraph_t graph;
         hipGraphExec_t exec;
         uint64_t last_use;
@@ -551,6 +553,16 @@ int ensure_foff(sbm_ctx* c, hipStream_t s)
     return 0;
 }
 
+// Form of level l's linear memories when the one-launch builder makes them: the refinement-only levels are ONE plane of
+// spread bytes (compact), strip-interleaved when the grid width allows it (the refinement pass reads 16 x 16 cells per
+// feature: 2 - 4 cache lines instead of 16)
+void lm_form(const sbm_ctx* c, int l, bool* compact, bool* strip)
+{
+    static const bool strip_ok = !(getenv("SBM_STRIP_LM") && atoi(getenv("SBM_STRIP_LM")) == 0); // A/B knob
+    *compact = l < c->L - 1 && c->d_lmc[l].p && use_compact_lm();
+    *strip = *compact && strip_ok && ((c->cols[l] / c->cfg.T[l]) & 15) == 0;
+}
+
 // gradient stage + linear memories for every level; d_img0 may be external
 // reset_count != null: the linear-memory launch also zeroes the per-frame counters and *reset_count
 // (c->counters_fresh tells enqueue_coarse to skip its own k_reset launch).
@@ -599,10 +611,8 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
         int blocks = 0;
         for (int l = 0; l < c->L; ++l) {
             const int T = c->cfg.T[l], W = c->cols[l] / T, H = c->rows[l] / T;
-            const bool compact = l < c->L - 1 && c->d_lmc[l].p && use_compact_lm();
-            // the refinement pass reads 16 x 16 cells per feature: strip-interleave the plane so that they are 2 - 4 lines
-            static const bool strip_ok = !(getenv("SBM_STRIP_LM") && atoi(getenv("SBM_STRIP_LM")) == 0); // A/B knob
-            const bool strip = compact && strip_ok && (W & 15) == 0;
+            bool compact, strip;
+            lm_form(c, l, &compact, &strip);
             a.lv[l] = LmLevelArgs{c->d_quant[l].as<uint8_t>(), compact ? c->d_lmc[l].as<uint8_t>() : c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
                                   c->rows[l], c->cols[l], W, H, T, blocks, (int64_t)c->rows[l] * c->cols[l],
                                   (int64_t)(compact ? 1 : 8) * c->lm_stride[l], strip ? 2 : (compact ? 1 : 0)};
@@ -771,6 +781,28 @@ int capture_match_graph(sbm_ctx* c, const uint8_t* d_img0, int stride0, const ui
             rc = fail(SBM_ERR_HIP, "graph join failed");
     }
     if (!rc) rc = enqueue_local(c, m, d_out, cap, d_count);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(m, &g);
+    if (rc) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess || !g) return fail(SBM_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    *graph = g;
+    return 0;
+}
+
+// The batched match loop (BASELINE config 5: "hipGraph-captured match loop") as one captured graph: the same five
+// launches sbm_match_batch_device enqueues (gradient stage per level, linear memories + counter reset, coarse pass,
+// refinement per level), recorded once per distinct argument tuple and replayed with one hipGraphLaunch per batch.
+int capture_batch_graph(sbm_ctx* c, const uint8_t* d_imgs, int64_t frame_stride, int frames, int stride0, const uint8_t* d_mask0,
+                        sbm_match_rec* d_out, int64_t cap, int32_t* d_counts, hipGraph_t* graph)
+{
+    hipStream_t m = c->stream;
+    HIP_TRY(hipStreamBeginCapture(m, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_pyramid(c, m, d_imgs, stride0, d_mask0, d_counts, frames, frame_stride);
+    if (!rc) rc = enqueue_coarse(c, m, d_out, cap, d_counts, frames);
+    if (!rc) rc = enqueue_local(c, m, d_out, cap, d_counts, frames);
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(m, &g);
     if (rc) {
@@ -1022,7 +1054,7 @@ int sbm_match_device(sbm_ctx* c, const void* d_img, int32_t rows, int32_t cols, 
     for (auto& g : c->graphs)
         if (g.img == d_img && g.rows == rows && g.cols == cols && g.stride == stride && g.ch == channels && g.mask == d_mask &&
             g.thr_bits == thr_bits && g.out == d_out && g.cap == cap && g.count == d_count && g.mo == (void*)c->mirror_out &&
-            g.mc == (void*)c->mirror_count)
+            g.mc == (void*)c->mirror_count && g.frames == 0)
             hit = &g;
     if (!hit) {
         if (c->graphs.size() >= 8) { // evict the least recently used capture
@@ -1035,7 +1067,7 @@ int sbm_match_device(sbm_ctx* c, const void* d_img, int32_t rows, int32_t cols, 
             c->graphs.erase(c->graphs.begin() + lru);
         }
         sbm_ctx::GraphEntry ge{d_img, rows, cols, stride, channels, d_mask, thr_bits, d_out, cap, d_count,
-                               (void*)c->mirror_out, (void*)c->mirror_count, nullptr, nullptr, 0};
+                               (void*)c->mirror_out, (void*)c->mirror_count, 0, 0, nullptr, nullptr, 0};
         if (int e = capture_match_graph(c, (const uint8_t*)d_img, stride, (const uint8_t*)d_mask, (sbm_match_rec*)d_out, cap,
                                         (int32_t*)d_count, &ge.graph))
             return e;
@@ -1074,6 +1106,51 @@ int sbm_match_batch_device(sbm_ctx* c, const void* d_imgs, int64_t frame_stride,
     if (int e = ensure_geometry(c, rows, cols, channels, n_frames)) return e;
     if (c->profiling && !c->profiling_keep) c->clear_timings();
     if (int e = prepare_templates(c, s, threshold, cap)) return e;
+    if (c->graph_mode && !c->profiling && n_frames > 1) {
+        // graph path: every state change happened above (they may synchronise); now one hipGraphLaunch per batch
+        uint32_t thr_bits;
+        memcpy(&thr_bits, &threshold, 4);
+        sbm_ctx::GraphEntry* hit = nullptr;
+        for (auto& g : c->graphs)
+            if (g.img == d_imgs && g.rows == rows && g.cols == cols && g.stride == stride && g.ch == channels && g.mask == d_mask &&
+                g.thr_bits == thr_bits && g.out == d_out && g.cap == cap && g.count == d_counts && g.mo == (void*)c->mirror_out &&
+                g.mc == (void*)c->mirror_count && g.frames == n_frames && g.frame_stride == frame_stride)
+                hit = &g;
+        if (!hit) {
+            if (c->graphs.size() >= 8) { // evict the least recently used capture
+                size_t lru = 0;
+                for (size_t i = 1; i < c->graphs.size(); ++i)
+                    if (c->graphs[i].last_use < c->graphs[lru].last_use) lru = i;
+                HIP_TRY(hipDeviceSynchronize());
+                (void)hipGraphExecDestroy(c->graphs[lru].exec);
+                (void)hipGraphDestroy(c->graphs[lru].graph);
+                c->graphs.erase(c->graphs.begin() + lru);
+            }
+            sbm_ctx::GraphEntry ge{d_imgs, rows, cols, stride, channels, d_mask, thr_bits, d_out, cap, d_counts,
+                                   (void*)c->mirror_out, (void*)c->mirror_count, n_frames, frame_stride, nullptr, nullptr, 0};
+            if (int e = capture_batch_graph(c, (const uint8_t*)d_imgs, frame_stride, n_frames, stride, (const uint8_t*)d_mask,
+                                            (sbm_match_rec*)d_out, cap, (int32_t*)d_counts, &ge.graph))
+                return e;
+            hipError_t he = hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0);
+            if (he != hipSuccess) {
+                (void)hipGraphDestroy(ge.graph);
+                return fail(SBM_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(he));
+            }
+            c->graphs.push_back(ge);
+            hit = &c->graphs.back();
+        }
+        hit->last_use = ++c->graph_clock;
+        c->levels_valid = c->L;
+        for (int l = 0; l < c->L; ++l) { // what the replay leaves resident (as enqueue_pyramid records it)
+            bool compact, strip;
+            lm_form(c, l, &compact, &strip);
+            c->lm_compact[l] = compact;
+            c->lm_full[l] = !compact;
+            c->lm_strip[l] = strip;
+        }
+        HIP_TRY(hipGraphLaunch(hit->exec, s));
+        return 0;
+    }
     if (int e = enqueue_pyramid(c, s, (const uint8_t*)d_imgs, stride, (const uint8_t*)d_mask, (int32_t*)d_counts, n_frames, frame_stride)) return e;
     if (int e = enqueue_coarse(c, s, (sbm_match_rec*)d_out, cap, (int32_t*)d_counts, n_frames)) return e;
     return enqueue_local(c, s, (sbm_match_rec*)d_out, cap, (int32_t*)d_counts, n_frames);

@@ -406,3 +406,61 @@ def test_batched_stream_config5_geometry(oracle, ctx_factory, case1):
         want = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 90.0)
         assert key(out[b].view(MATCH_DTYPE)[: cnt[b, 0]]) == key(want), b
         pyr.free()
+
+
+def test_match_batch_device_graph_replay(oracle, ctx_factory, case1):
+    """BASELINE config 5's "hipGraph-captured match loop": sbm_match_batch_device in graph mode captures the batch's
+    launches once per argument tuple and replays them; lists must equal the oracle's per frame, across replays, after
+    the frames' pixels change in place, next to plain-stream calls, and with the pinned result mirror"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    ts = case1["templates"].subset(range(280, 361, 2))
+    base = frame_of(case1)
+    frames = [base, np.ascontiguousarray(base[:, ::-1]), np.roll(base, 48, axis=1), np.zeros_like(base)]
+    rows, cols = base.shape[:2]
+    thr = 80.0
+    want = []
+    for fr in frames:
+        pyr = oracle.Pyramid.build(fr, [4, 8], 30.0)
+        want.append(pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr))
+        pyr.free()
+    assert len(want[0]) > 0
+    ctx = ctx_factory()
+    ctx.upload_templates(ts)
+    cap, rec, B = 1024, MATCH_DTYPE.itemsize, len(frames)
+    stream = torch.cuda.Stream(device=dev)
+    d_imgs = torch.from_numpy(np.stack(frames)).to(dev)
+    d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(B * 2, dtype=torch.int32, device=dev)
+    h_out = torch.zeros(B * cap * rec, dtype=torch.uint8).pin_memory()
+    h_cnt = torch.zeros(B * 2, dtype=torch.int32).pin_memory()
+    fs = rows * cols * 3
+
+    def run_and_check(order, mirror):
+        d_cnt.fill_(-1)
+        ctx.match_batch_device(d_imgs.data_ptr(), fs, B, rows, cols, cols * 3, 3, thr, d_out.data_ptr(), cap, d_cnt.data_ptr(),
+                               stream=stream.cuda_stream)
+        stream.synchronize()
+        cnt = d_cnt.cpu().numpy().reshape(-1, 2)
+        out = d_out.cpu().numpy().reshape(B, cap * rec)
+        for f in range(B):
+            w = want[order[f]]
+            assert cnt[f, 1] == 0 and cnt[f, 0] == len(w), (order, f)
+            assert key(out[f].view(MATCH_DTYPE)[: cnt[f, 0]]) == key(w)
+            if mirror:
+                hc = h_cnt.numpy().reshape(-1, 2)
+                assert hc[f, 0] == cnt[f, 0]
+                assert key(h_out.numpy().reshape(B, cap * rec)[f].view(MATCH_DTYPE)[: hc[f, 0]]) == key(w)
+
+    for mirror in (False, True):
+        ctx.set_result_mirror(h_out.data_ptr() if mirror else 0, h_cnt.data_ptr() if mirror else 0)
+        for graph in (True, False, True):
+            ctx.set_graph_mode(graph)
+            order = [0, 1, 2, 3]
+            d_imgs.copy_(torch.from_numpy(np.stack([frames[i] for i in order])).to(dev))
+            for _ in range(3):  # capture, then replays
+                run_and_check(order, mirror)
+            order = [2, 3, 0, 1]  # same buffers, other pixels: the replayed graph reads the buffer, not a snapshot
+            d_imgs.copy_(torch.from_numpy(np.stack([frames[i] for i in order])).to(dev))
+            run_and_check(order, mirror)
