@@ -89,6 +89,12 @@ int64_t lm_stride_for(int rows, int cols, int T)
 
 } // namespace
 
+static int coarse_mode_env()
+{
+    const char* env = getenv("SBM_COARSE");
+    return env && !strcmp(env, "block") ? 1 : (env && !strcmp(env, "wave") ? 2 : 0);
+}
+
 struct sbm_ctx {
     sbm_config cfg{};
     int L = 0;
@@ -166,6 +172,7 @@ struct sbm_ctx {
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
     int quantize_mode = 0, quantize_hs = 0; // sbm_set_quantize_mode
+    int coarse_mode = coarse_mode_env();    // 0 auto, 1 four waves per item, 2 one wave per item (SBM_COARSE=block|wave: A/B knob)
     bool graph_mode = false; // measured on ROCm 7.2 / MI355X: graph replay is slower than stream launches
     hipStream_t side = nullptr;
     hipEvent_t ev_fork[SBM_MAX_LEVELS] = {};
@@ -673,11 +680,21 @@ int enqueue_coarse(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap,
         }
         for (int first = 0; first < n_active; first += 65535) {
             const int cnt = std::min(65535, n_active - first);
-            SBM_LAUNCH(c, "k_similarity_coarse", k_similarity_coarse, dim3(chunks, cnt, frames), dim3(256), 0, s, c->d_lm[lc].as<uint8_t>(),
-                               c->lm_stride[lc], c->rows[lc], c->cols[lc], T, W, H, L, lc, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(),
-                               c->d_foff.as<int32_t>(), c->d_active.as<int32_t>() + first, c->d_rawmin.as<int32_t>(),
-                               c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
-                               c->d_cands.as<Cand>(), counters, (int)c->cand_cap, (int64_t)8 * c->lm_stride[lc]);
+            // large launches: one wave per (chunk, template, frame); small ones (a single frame with a few hundred
+            // templates): four waves share an item's features so that enough loads are in flight
+            const bool per_wave = c->coarse_mode == 2 || (c->coarse_mode == 0 && (int64_t)chunks * cnt * frames >= 8192);
+            if (per_wave)
+                SBM_LAUNCH(c, "k_similarity_coarse", k_similarity_coarse_wave, dim3(chunks, (cnt + 3) / 4, frames), dim3(256), 0, s,
+                           c->d_lm[lc].as<uint8_t>(), c->lm_stride[lc], c->rows[lc], c->cols[lc], T, W, H, L, lc, c->d_tls.as<DevTL>(),
+                           c->d_fxy.as<uint32_t>(), c->d_foff.as<int32_t>(), c->d_active.as<int32_t>() + first, cnt,
+                           c->d_rawmin.as<int32_t>(), c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
+                           c->d_cands.as<Cand>(), counters, (int)c->cand_cap, (int64_t)8 * c->lm_stride[lc]);
+            else
+                SBM_LAUNCH(c, "k_similarity_coarse", k_similarity_coarse, dim3(chunks, cnt, frames), dim3(256), 0, s, c->d_lm[lc].as<uint8_t>(),
+                           c->lm_stride[lc], c->rows[lc], c->cols[lc], T, W, H, L, lc, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(),
+                           c->d_foff.as<int32_t>(), c->d_active.as<int32_t>() + first, c->d_rawmin.as<int32_t>(),
+                           c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
+                           c->d_cands.as<Cand>(), counters, (int)c->cand_cap, (int64_t)8 * c->lm_stride[lc]);
         }
         HIP_TRY(hipGetLastError());
     }

@@ -1242,6 +1242,7 @@ __device__ __forceinline__ int unpack4(uint32_t lo, uint32_t hi, int k)
 // ~12 TB/s, twice the rate of dword loads and of byte-misaligned dwordx4.
 // j0 must be a multiple of 4.  Same calling convention as accumulate_features
 // (all 64 lanes active).  lo[i]/hi[i]: packed u16 sums of bytes 4i..4i+3.
+template <bool RESET = true>
 __device__ __forceinline__ void accumulate_features16(const uint8_t* __restrict__ lm,
                                                       const uint32_t* __restrict__ fxy,
                                                       const int32_t* __restrict__ foff, int count,
@@ -1251,8 +1252,10 @@ __device__ __forceinline__ void accumulate_features16(const uint8_t* __restrict_
     const int lane = threadIdx.x & 63;
     const uint8_t* p = lm + j0;
     uint32_t acc[4] = {0, 0, 0, 0};
+    if (RESET) { // RESET == false: add to the sums the caller already holds
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lo[i] = hi[i] = 0;
+        for (int i = 0; i < 4; ++i) lo[i] = hi[i] = 0;
+    }
     int pending = 0;
     count = __builtin_amdgcn_readfirstlane(count); // wave-uniform by contract: keep the loop control scalar
     for (int b = 0; b < count; b += 64) {
@@ -1337,6 +1340,60 @@ __global__ void k_reset(int32_t* __restrict__ counters, int32_t* __restrict__ ou
     if (threadIdx.x < 2) out_count[threadIdx.x] = 0;
 }
 
+typedef unsigned short coarse_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t coarse_pk_max_u16(uint32_t a, uint32_t b) // v_pk_max_u16
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(coarse_us2, a), __builtin_bit_cast(coarse_us2, b)));
+}
+
+// Which (position chunk, template slot, frame) a workgroup of the coarse pass works on.  Pure speed: any bijection
+// of the grid is correct.
+__device__ __forceinline__ void coarse_block_item(int& chunk_id, int& templ_slot, int& frame)
+{
+    chunk_id = blockIdx.x, templ_slot = blockIdx.y, frame = blockIdx.z;
+    const bool frame_affinity = (gridDim.z & 7) == 0;
+    if (frame_affinity) {
+        // Workgroups are dealt to the 8 XCDs round-robin by linear id and each XCD has its own 4 MiB L2.  With a batch
+        // of 8k frames give XCD x the frames x, x+8, ... one after the other: its L2 then holds ONE frame's linear
+        // memories at a time (2 MiB on the bench configuration) instead of every frame's.
+        const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const uint32_t xcd = lin & 7, j = lin >> 3, per = gridDim.x * gridDim.y;
+        const uint32_t fl = j / per, rem = j - fl * per;
+        frame = (int)(xcd + 8 * fl);
+        templ_slot = (int)(rem / gridDim.x);
+        chunk_id = (int)(rem - (uint32_t)templ_slot * gridDim.x);
+    }
+    // XCD-aware (chunk, template) assignment: give XCD x the position chunks [x*cpx, (x+1)*cpx) of EVERY
+    // template, so that one L2 only ever sees the slice of the linear memories those chunks read
+    // (chunk span + template extent) instead of all of them.
+    if (!frame_affinity && (gridDim.x & 7) == 0) {
+        const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+        const int cpx = (int)gridDim.x >> 3;
+        const int xcd = lin & 7, slot = lin >> 3;
+        templ_slot = slot / cpx;
+        // the chunk ranges rotate over the XCDs every 64 templates: ranges past the templates' span are
+        // empty, and this spreads them evenly while an XCD still works on one slice for 64 templates
+        chunk_id = ((xcd + (templ_slot >> 6)) & 7) * cpx + slot % cpx;
+    }
+}
+
+// The prefix length k1 and the partial-sum bound thr1 of the coarse pass's exact pruning.  A feature adds at most 4,
+// so after the first k1 of nf features a position whose partial sum is below rmin - 4*(nf - k1) cannot reach rmin any
+// more.  k1 is the shortest prefix (multiple of 4, at least 8) for which that bound is at least 62.5 % of the
+// prefix's own maximum 4*k1 (a weaker bound prunes little on busy images); k1 == nf means no pruning.
+__device__ __forceinline__ void coarse_prune_split(int nf, int rmin, int& k1, int& thr1)
+{
+    k1 = nf, thr1 = 0;
+    if (rmin > 0) {
+        int k = ((4 * nf - rmin) * 5 + 7) >> 3;
+        k = ((k < 8 ? 8 : k) + 3) & ~3;
+        if (4 * k <= 3 * nf) {
+            k1 = k;
+            thr1 = rmin - 4 * (nf - k1);
+        }
+    }
+}
+
 // grid = (position chunks of 1024, active templates); block = 4 waves.  Every
 // wave covers the same 1024 positions (16 per lane) for a contiguous quarter
 // of the template's features, so four times as many loads are in flight per
@@ -1353,36 +1410,13 @@ __global__ __launch_bounds__(256) void k_similarity_coarse(
 {
     // batch of frames: per-frame linear memories, candidate list and counters
     __shared__ uint32_t s_red[4][8][64];
+    __shared__ int s_alive[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int chunk_id = blockIdx.x, templ_slot = blockIdx.y, frame = blockIdx.z;
-    const bool frame_affinity = (gridDim.z & 7) == 0;
-    if (frame_affinity) {
-        // Workgroups are dealt to the 8 XCDs round-robin by linear id and each XCD has its own 4 MiB L2.  With a batch
-        // of 8k frames give XCD x the frames x, x+8, ... one after the other: its L2 then holds ONE frame's linear
-        // memories at a time (2 MiB on the bench configuration) instead of every frame's.  Pure speed.
-        const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const uint32_t xcd = lin & 7, j = lin >> 3, per = gridDim.x * gridDim.y;
-        const uint32_t fl = j / per, rem = j - fl * per;
-        frame = (int)(xcd + 8 * fl);
-        templ_slot = (int)(rem / gridDim.x);
-        chunk_id = (int)(rem - (uint32_t)templ_slot * gridDim.x);
-    }
+    int chunk_id, templ_slot, frame;
+    coarse_block_item(chunk_id, templ_slot, frame);
     lm += (size_t)frame * lm_fs;
     cands += (size_t)frame * cap;
     counters += (size_t)frame * 40;
-    // XCD-aware (chunk, template) assignment.  Workgroups are dealt to the 8 XCDs round-robin by linear id,
-    // and each XCD has its own 4 MiB L2: give XCD x the position chunks [x*cpx, (x+1)*cpx) of EVERY
-    // template, so that one L2 only ever sees the slice of the linear memories those chunks read
-    // (chunk span + template extent) instead of all of them.  Pure speed: any mapping is correct.
-    if (!frame_affinity && (gridDim.x & 7) == 0) {
-        const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
-        const int cpx = (int)gridDim.x >> 3;
-        const int xcd = lin & 7, slot = lin >> 3;
-        templ_slot = slot / cpx;
-        // the chunk ranges rotate over the XCDs every 64 templates: ranges past the templates' span are
-        // empty, and this spreads them evenly while an XCD still works on one slice for 64 templates
-        chunk_id = ((xcd + (templ_slot >> 6)) & 7) * cpx + slot % cpx;
-    }
     const int t = active[templ_slot];
     const DevTL tl = tls[(size_t)t * L + lc];
     const int npos = template_positions(tl, W, H, T);
@@ -1392,28 +1426,51 @@ __global__ __launch_bounds__(256) void k_similarity_coarse(
     if (base >= total) return;
     if (base >= npos && rmin > 0) return; // beyond the span every score is 0
     const int j0 = base + lane * 16;
-    uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
-    if (base < npos) { // block-uniform: every lane takes part (features are spread over the wave's lanes)
-        const int zero_off = (int)(7 * lm_stride + (int64_t)T * T * W * H); // zero tail of the last orientation
-        // lanes past the span take no part in the loads (one extra lane does: its first dword is its
-        // left neighbour's bytes 16..19)
-        const bool lane_on = j0 < npos + 16;
-        const int chunk = (tl.nf + 3) >> 2;
-        const int f0 = wave * chunk;
-        int cnt = tl.nf - f0;
-        cnt = cnt < 0 ? 0 : (cnt > chunk ? chunk : cnt);
-        accumulate_features16(lm, fxy + tl.feat_off + f0, foff + tl.feat_off + f0, cnt, rows, cols, lane_on ? j0 : 0, lane_on,
-                              zero_off, lo, hi);
-    }
+    const int zero_off = (int)(7 * lm_stride + (int64_t)T * T * W * H); // zero tail of the last orientation
+    // lanes past the span take no part in the loads (one extra lane does: its first dword is its
+    // left neighbour's bytes 16..19)
+    const bool lane_on = j0 < npos + 16;
+    // features [fb, fe) over the block's 1024 positions: a quarter of them per wave, partial sums meet in LDS;
+    // returns the packed sums of positions j0 + 4*wave .. +3 of every lane
+    auto partial = [&](int fb, int fe, uint32_t& slo, uint32_t& shi) {
+        uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+        if (base < npos) { // block-uniform: every lane takes part (features are spread over the wave's lanes)
+            const int chunk = (fe - fb + 3) >> 2;
+            const int f0 = fb + wave * chunk;
+            int cnt = fe - f0;
+            cnt = cnt < 0 ? 0 : (cnt > chunk ? chunk : cnt);
+            accumulate_features16(lm, fxy + tl.feat_off + f0, foff + tl.feat_off + f0, cnt, rows, cols, lane_on ? j0 : 0,
+                                  lane_on, zero_off, lo, hi);
+        }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        s_red[wave][i][lane] = lo[i];
-        s_red[wave][4 + i][lane] = hi[i];
+        for (int i = 0; i < 4; ++i) {
+            s_red[wave][i][lane] = lo[i];
+            s_red[wave][4 + i][lane] = hi[i];
+        }
+        __syncthreads();
+        slo = s_red[0][wave][lane] + s_red[1][wave][lane] + s_red[2][wave][lane] + s_red[3][wave][lane];
+        shi = s_red[0][4 + wave][lane] + s_red[1][4 + wave][lane] + s_red[2][4 + wave][lane] + s_red[3][4 + wave][lane];
+    };
+    // Exact pruning in two phases (coarse_prune_split): the block stops after the prefix unless one of its 1024
+    // positions is still alive.  The candidate set is the same as without pruning: nothing is dropped that could
+    // have reached rmin.
+    int k1, thr1;
+    coarse_prune_split(tl.nf, rmin, k1, thr1);
+    uint32_t slo, shi;
+    partial(0, k1, slo, shi);
+    if (k1 < tl.nf) {
+        bool alive = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) alive |= (j0 + 4 * wave + k < npos) && unpack4(slo, shi, k) >= thr1;
+        if (lane == 0) s_alive[wave] = 0;
+        if (__builtin_amdgcn_ballot_w64(alive) != 0ull && lane == 0) s_alive[wave] = 1;
+        __syncthreads(); // also: every wave has read s_red before the second phase rewrites it
+        if ((s_alive[0] | s_alive[1] | s_alive[2] | s_alive[3]) == 0) return;
+        uint32_t lo2, hi2;
+        partial(k1, tl.nf, lo2, hi2);
+        slo += lo2;
+        shi += hi2;
     }
-    __syncthreads();
-    // wave w scans positions j0 + 4w .. j0 + 4w + 3 of every lane
-    const uint32_t slo = s_red[0][wave][lane] + s_red[1][wave][lane] + s_red[2][wave][lane] + s_red[3][wave][lane];
-    const uint32_t shi = s_red[0][4 + wave][lane] + s_red[1][4 + wave][lane] + s_red[2][4 + wave][lane] + s_red[3][4 + wave][lane];
     const int offset = T / 2 + (T % 2 - 1);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1430,6 +1487,78 @@ __global__ __launch_bounds__(256) void k_similarity_coarse(
                 c.raw = raw;
                 cand_fill_next(c, tls, raw_keep, class_idx, template_id, L, lc - 1);
                 cands[idx] = c;
+            }
+        }
+    }
+}
+
+// The coarse pass for large launches (batches of frames, thousands of templates): one WAVE per (position chunk,
+// template, frame), four such items per workgroup (template slots 4*blockIdx.y .. +3), no LDS and no barrier.
+// With the exact pruning most waves stop after the first k1 features, so splitting a template's features over four
+// waves (the kernel above, which keeps single-frame latency low) only multiplies the per-item overhead; here a
+// wave's life is its metadata fetch plus k1/8 load batches, and the launch is bound by L2 bandwidth instead of by
+// the number of workgroups in flight.  Same arguments, same candidates.
+__global__ __launch_bounds__(256) void k_similarity_coarse_wave(
+    const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int lc,
+    const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
+    const int32_t* __restrict__ active, int n_active, const int32_t* __restrict__ raw_min, const int32_t* __restrict__ raw_keep,
+    const int32_t* __restrict__ class_idx, const int32_t* __restrict__ template_id, Cand* __restrict__ cands,
+    int32_t* __restrict__ counters, int cap, int64_t lm_fs)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int chunk_id, slot4, frame;
+    coarse_block_item(chunk_id, slot4, frame);
+    const int templ_slot = slot4 * 4 + wave;
+    if (templ_slot >= n_active) return;
+    lm += (size_t)frame * lm_fs;
+    cands += (size_t)frame * cap;
+    counters += (size_t)frame * 40;
+    const int t = active[templ_slot];
+    const DevTL tl = tls[(size_t)t * L + lc];
+    const int npos = template_positions(tl, W, H, T);
+    const int rmin = raw_min[(size_t)t * L + lc];
+    const int base = chunk_id * COARSE_POS_PER_BLOCK;
+    const int total = W * H;
+    if (base >= total) return;
+    if (base >= npos && rmin > 0) return; // beyond the span every score is 0
+    const int j0 = base + lane * 16;
+    uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+    if (base < npos) {
+        const int zero_off = (int)(7 * lm_stride + (int64_t)T * T * W * H);
+        const bool lane_on = j0 < npos + 16;
+        int k1, thr1;
+        coarse_prune_split(tl.nf, rmin, k1, thr1);
+        accumulate_features16(lm, fxy + tl.feat_off, foff + tl.feat_off, k1, rows, cols, lane_on ? j0 : 0, lane_on, zero_off, lo, hi);
+        if (k1 < tl.nf) {
+            // alive: one of the lane's 16 partial sums >= thr1 (positions past the span may hold anything and only
+            // cost time: the scan below zeroes them)
+            uint32_t m = coarse_pk_max_u16(coarse_pk_max_u16(coarse_pk_max_u16(lo[0], hi[0]), coarse_pk_max_u16(lo[1], hi[1])),
+                                           coarse_pk_max_u16(coarse_pk_max_u16(lo[2], hi[2]), coarse_pk_max_u16(lo[3], hi[3])));
+            const int best = (int)((m & 0xffff) > (m >> 16) ? (m & 0xffff) : (m >> 16));
+            if (__builtin_amdgcn_ballot_w64(best >= thr1) == 0ull) return;
+            accumulate_features16<false>(lm, fxy + tl.feat_off + k1, foff + tl.feat_off + k1, tl.nf - k1, rows, cols,
+                                         lane_on ? j0 : 0, lane_on, zero_off, lo, hi);
+        }
+    }
+    const int offset = T / 2 + (T % 2 - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + 4 * i + k;
+            int raw = unpack4(lo[i], hi[i], k);
+            if (j >= npos) raw = 0;
+            if (j < total && raw >= rmin) {
+                int idx = atomicAdd(&counters[0], 1);
+                if (idx < cap) {
+                    Cand c;
+                    c.t = t;
+                    c.x = (j % W) * T + offset;
+                    c.y = (j / W) * T + offset;
+                    c.raw = raw;
+                    cand_fill_next(c, tls, raw_keep, class_idx, template_id, L, lc - 1);
+                    cands[idx] = c;
+                }
             }
         }
     }
