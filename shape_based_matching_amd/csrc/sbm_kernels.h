@@ -1324,6 +1324,94 @@ __device__ __forceinline__ void accumulate_features16(const uint8_t* __restrict_
     }
 }
 
+typedef unsigned short coarse_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t coarse_pk_max_u16(uint32_t a, uint32_t b) // v_pk_max_u16
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(coarse_us2, a), __builtin_bit_cast(coarse_us2, b)));
+}
+
+// accumulate_features16 with exact pruning, for a wave that owns ALL nf features of its item.  A feature adds at
+// most 4, so once `done` features are in, a position whose partial sum is below rmin - 4*(nf - done) cannot reach
+// rmin any more; after every batch of 8 features (as soon as that bound exceeds half the prefix's own maximum
+// 4*done -- a weaker bound prunes little and rmin <= 2*nf never gets there) the wave looks whether any of its 1024
+// positions is still alive and returns false if none is.  Positions past the template's span may hold anything:
+// they can only keep the wave going, the caller's scan ignores them.  Returns true with the complete sums.
+__device__ __forceinline__ bool accumulate_features16_pruned(const uint8_t* __restrict__ lm, const uint32_t* __restrict__ fxy,
+                                                             const int32_t* __restrict__ foff, int nf, int rows, int cols,
+                                                             int j0, bool lane_on, int zero_off, int rmin,
+                                                             uint32_t (&lo)[4], uint32_t (&hi)[4])
+{
+    const int lane = threadIdx.x & 63;
+    const uint8_t* p = lm + j0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lo[i] = hi[i] = 0;
+    nf = __builtin_amdgcn_readfirstlane(nf);
+    rmin = __builtin_amdgcn_readfirstlane(rmin);
+    for (int b = 0; b < nf; b += 64) {
+        int sel = zero_off;
+        if (b + lane < nf) {
+            const uint32_t xy = fxy[b + lane];
+            const int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
+            if (x < cols && y < rows) sel = foff[b + lane];
+        }
+        const int nb = nf - b < 64 ? nf - b : 64;
+        auto batch = [&](auto N, int u) {
+            constexpr int n = decltype(N)::value;
+            u128_a4 q[n];
+            uint32_t e[n];
+            int sh[n];
+            if (lane_on) {
+#pragma unroll
+                for (int k = 0; k < n; ++k) {
+                    const int o = __builtin_amdgcn_readlane(sel, (u + k) & 63);
+                    sh[k] = o & 3;
+                    const uint8_t* a = p + (o & ~3);
+                    q[k] = *(const u128_a4*)a;
+                    e[k] = 0;
+                    if (lane == 63) e[k] = *(const uint32_t*)(a + 16);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < n; ++k) {
+                    q[k] = u128_a4{0, 0, 0, 0};
+                    e[k] = 0;
+                    sh[k] = 0;
+                }
+            }
+            uint32_t acc[4] = {0, 0, 0, 0}; // byte sums of at most 8 features
+#pragma unroll
+            for (int k = 0; k < n; ++k) {
+                const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)e[k], (int)q[k].x, 0x130, 0xf, 0xf, false);
+                acc[0] += __builtin_amdgcn_alignbyte(q[k].y, q[k].x, sh[k]);
+                acc[1] += __builtin_amdgcn_alignbyte(q[k].z, q[k].y, sh[k]);
+                acc[2] += __builtin_amdgcn_alignbyte(q[k].w, q[k].z, sh[k]);
+                acc[3] += __builtin_amdgcn_alignbyte(nx, q[k].w, sh[k]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lo[i] += acc[i] & 0x00ff00ffu;
+                hi[i] += (acc[i] >> 8) & 0x00ff00ffu;
+            }
+        };
+        int u = 0;
+        for (; u + FB16 <= nb; u += FB16) {
+            batch(std::integral_constant<int, FB16>{}, u);
+            const int done = b + u + FB16;
+            const int bound = rmin - 4 * (nf - done);
+            if (bound > 0 && done < nf) {
+                const uint32_t m = coarse_pk_max_u16(coarse_pk_max_u16(coarse_pk_max_u16(lo[0], hi[0]), coarse_pk_max_u16(lo[1], hi[1])),
+                                                     coarse_pk_max_u16(coarse_pk_max_u16(lo[2], hi[2]), coarse_pk_max_u16(lo[3], hi[3])));
+                const int best = (int)((m & 0xffff) > (m >> 16) ? (m & 0xffff) : (m >> 16));
+                if (__builtin_amdgcn_ballot_w64(best >= bound) == 0ull) return false;
+            }
+        }
+        if (nb - u >= 4) { batch(std::integral_constant<int, 4>{}, u); u += 4; }
+        if (nb - u >= 2) { batch(std::integral_constant<int, 2>{}, u); u += 2; }
+        if (nb - u >= 1) batch(std::integral_constant<int, 1>{}, u);
+    }
+    return true;
+}
+
 // plain byte copy (gathered match lists -> pinned host mirror); n multiple of 8 by construction
 __global__ __launch_bounds__(256) void k_copy_bytes(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t n)
 {
@@ -1338,12 +1426,6 @@ __global__ void k_reset(int32_t* __restrict__ counters, int32_t* __restrict__ ou
 {
     if (threadIdx.x < 40) counters[threadIdx.x] = 0; // [0] candidates [2,3] refine bytes [4] arrivals [8..39] sub-arrivals
     if (threadIdx.x < 2) out_count[threadIdx.x] = 0;
-}
-
-typedef unsigned short coarse_us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t coarse_pk_max_u16(uint32_t a, uint32_t b) // v_pk_max_u16
-{
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(coarse_us2, a), __builtin_bit_cast(coarse_us2, b)));
 }
 
 // Which (position chunk, template slot, frame) a workgroup of the coarse pass works on.  Pure speed: any bijection
@@ -1494,10 +1576,9 @@ __global__ __launch_bounds__(256) void k_similarity_coarse(
 
 // The coarse pass for large launches (batches of frames, thousands of templates): one WAVE per (position chunk,
 // template, frame), four such items per workgroup (template slots 4*blockIdx.y .. +3), no LDS and no barrier.
-// With the exact pruning most waves stop after the first k1 features, so splitting a template's features over four
-// waves (the kernel above, which keeps single-frame latency low) only multiplies the per-item overhead; here a
-// wave's life is its metadata fetch plus k1/8 load batches, and the launch is bound by L2 bandwidth instead of by
-// the number of workgroups in flight.  Same arguments, same candidates.
+// With the exact pruning (accumulate_features16_pruned: re-checked after every 8 features) most waves stop after
+// two or three batches, so splitting a template's features over four waves (the kernel above, which keeps
+// single-frame latency low) only multiplies the per-item overhead.  Same arguments, same candidates.
 __global__ __launch_bounds__(256) void k_similarity_coarse_wave(
     const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int lc,
     const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
@@ -1526,19 +1607,9 @@ __global__ __launch_bounds__(256) void k_similarity_coarse_wave(
     if (base < npos) {
         const int zero_off = (int)(7 * lm_stride + (int64_t)T * T * W * H);
         const bool lane_on = j0 < npos + 16;
-        int k1, thr1;
-        coarse_prune_split(tl.nf, rmin, k1, thr1);
-        accumulate_features16(lm, fxy + tl.feat_off, foff + tl.feat_off, k1, rows, cols, lane_on ? j0 : 0, lane_on, zero_off, lo, hi);
-        if (k1 < tl.nf) {
-            // alive: one of the lane's 16 partial sums >= thr1 (positions past the span may hold anything and only
-            // cost time: the scan below zeroes them)
-            uint32_t m = coarse_pk_max_u16(coarse_pk_max_u16(coarse_pk_max_u16(lo[0], hi[0]), coarse_pk_max_u16(lo[1], hi[1])),
-                                           coarse_pk_max_u16(coarse_pk_max_u16(lo[2], hi[2]), coarse_pk_max_u16(lo[3], hi[3])));
-            const int best = (int)((m & 0xffff) > (m >> 16) ? (m & 0xffff) : (m >> 16));
-            if (__builtin_amdgcn_ballot_w64(best >= thr1) == 0ull) return;
-            accumulate_features16<false>(lm, fxy + tl.feat_off + k1, foff + tl.feat_off + k1, tl.nf - k1, rows, cols,
-                                         lane_on ? j0 : 0, lane_on, zero_off, lo, hi);
-        }
+        if (!accumulate_features16_pruned(lm, fxy + tl.feat_off, foff + tl.feat_off, tl.nf, rows, cols, lane_on ? j0 : 0, lane_on,
+                                          zero_off, rmin, lo, hi))
+            return; // no position of this item can reach rmin
     }
     const int offset = T / 2 + (T % 2 - 1);
 #pragma unroll
