@@ -414,8 +414,18 @@ int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, i
         a.n_strips = (cols + QS_USEFUL - 1) / QS_USEFUL;
         a.n_rblocks = (rows + hs - 1) / hs;
         const dim3 g((unsigned)((a.n_strips * a.n_rblocks + 3) / 4), (unsigned)frames);
-        if (ch == 1) SBM_LAUNCH(c, "k_quantize", (k_quantize_stream<1>), g, dim3(256), 0, s, a);
-        else SBM_LAUNCH(c, "k_quantize", (k_quantize_stream<3>), g, dim3(256), 0, s, a);
+        // experiment knob: dynamic LDS the kernel never touches, to cap the workgroups per CU (waves per SIMD)
+        static const int lds_pad = getenv("SBM_QS_LDS") ? atoi(getenv("SBM_QS_LDS")) : 0;
+        if (lds_pad > 0) {
+            static bool once = false;
+            if (!once) {
+                once = true;
+                (void)hipFuncSetAttribute((const void*)k_quantize_stream<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
+                (void)hipFuncSetAttribute((const void*)k_quantize_stream<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
+            }
+        }
+        if (ch == 1) SBM_LAUNCH(c, "k_quantize", (k_quantize_stream<1>), g, dim3(256), lds_pad, s, a);
+        else SBM_LAUNCH(c, "k_quantize", (k_quantize_stream<3>), g, dim3(256), lds_pad, s, a);
         HIP_TRY(hipGetLastError());
         return 0;
     }
