@@ -28,11 +28,14 @@ def per_kernel(path, counter):
 
 fetch = per_kernel(sys.argv[1], 'FETCH_SIZE')
 write = per_kernel(sys.argv[2], 'WRITE_SIZE')
-wide = {'k_build_lm_rows', 'k_similarity_coarse'}
+wide = {'k_build_lm_rows', 'k_similarity_coarse', 'k_similarity_coarse_wave'}
 out = {'_unit': 'bytes per launch (average over the launches of one step)', '_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes', '_raw_KiB': {}}
 # the step's gradient launches are the row-streaming kernel; the 16 x 64 tile kernel only serves the single-frame
 # verification calls of bench.py and keeps its own key
 alias = {'k_build_lm_rows': 'k_build_lm', 'k_quantize_stream': 'k_quantize', 'k_quantize': 'k_quantize_tile'} if 'k_quantize_stream' in (set(fetch) | set(write)) else {'k_build_lm_rows': 'k_build_lm'}
+# likewise the batch's coarse pass is the one-wave-per-item kernel; the four-wave kernel serves single frames
+if 'k_similarity_coarse_wave' in (set(fetch) | set(write)):
+    alias.update({'k_similarity_coarse_wave': 'k_similarity_coarse', 'k_similarity_coarse': 'k_similarity_coarse_block'})
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     fc = f * (2.0 if k in wide else 1.0)
