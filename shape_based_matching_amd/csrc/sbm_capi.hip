@@ -482,8 +482,8 @@ int launch_build_lm(sbm_ctx* c, hipStream_t s, const uint8_t* d_q, int rows, int
         LmArgs a;
         memset(&a, 0, sizeof a);
         a.n_levels = 1;
-        a.lv[0] = LmLevelArgs{d_q, d_lm, lm_stride, rows, cols, W, H, T, 0, 0, 0, 0};
-        const int64_t items = (int64_t)rows * (W >> 2);
+        a.lv[0] = LmLevelArgs{d_q, d_lm, lm_stride, rows, cols, W, H, T, 0, 0, 0, 0, LM_FULL_SPLIT};
+        const int64_t items = (int64_t)rows * (W >> 2) * LM_FULL_SPLIT;
         SBM_LAUNCH(c, "k_build_lm", k_build_lm_rows, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
         HIP_TRY(hipGetLastError());
         return 0;
@@ -626,17 +626,22 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
         memset(&a, 0, sizeof a);
         a.n_levels = c->L;
         int blocks = 0;
-        for (int l = 0; l < c->L; ++l) {
+        // block ranges coarsest level first: its blocks (T * 8 / 4 stores per lane) are the long ones, and a launch
+        // that dispatches its long blocks last ends with a few of them running alone
+        for (int l = c->L - 1; l >= 0; --l) {
             const int T = c->cfg.T[l], W = c->cols[l] / T, H = c->rows[l] / T;
             bool compact, strip;
             lm_form(c, l, &compact, &strip);
+            const int split = frames < 4 ? LM_FULL_SPLIT : 1; // few frames: shorter, more numerous work items
             a.lv[l] = LmLevelArgs{c->d_quant[l].as<uint8_t>(), compact ? c->d_lmc[l].as<uint8_t>() : c->d_lm[l].as<uint8_t>(), c->lm_stride[l],
                                   c->rows[l], c->cols[l], W, H, T, blocks, (int64_t)c->rows[l] * c->cols[l],
-                                  (int64_t)(compact ? 1 : 8) * c->lm_stride[l], strip ? 2 : (compact ? 1 : 0)};
+                                  (int64_t)(compact ? 1 : 8) * c->lm_stride[l], strip ? 2 : (compact ? 1 : 0), split};
             c->lm_compact[l] = compact;
             c->lm_strip[l] = strip;
             c->lm_full[l] = !compact;
-            const int64_t items = strip ? (int64_t)(W >> 4) * ((H + 15) >> 4) * T * 64 : (int64_t)c->rows[l] * (W >> 2);
+            const int64_t items = strip     ? (int64_t)(W >> 4) * ((H + 15) >> 4) * T * 64
+                                  : compact ? (int64_t)c->rows[l] * (W >> 2)
+                                            : (int64_t)c->rows[l] * (W >> 2) * split;
             blocks += (int)((items + 255) / 256);
         }
         if (reset_count) {
