@@ -639,7 +639,7 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
             c->lm_compact[l] = compact;
             c->lm_strip[l] = strip;
             c->lm_full[l] = !compact;
-            const int64_t items = strip     ? (int64_t)(W >> 4) * ((H + 15) >> 4) * T * 64
+            const int64_t items = strip     ? (int64_t)((W + 63) >> 6) * ((H + 15) >> 4) * T * 256
                                   : compact ? (int64_t)c->rows[l] * (W >> 2)
                                             : (int64_t)c->rows[l] * (W >> 2) * split;
             blocks += (int)((items + 255) / 256);

@@ -866,23 +866,30 @@ constexpr int LM_FULL_SPLIT = 4; // work items per (pixel row, 4 cells) of a lev
 template <int T>
 __device__ __forceinline__ void build_lm_rows_item(const uint8_t* __restrict__ q, int rows, int cols, int W, int H,
                                                    uint8_t* __restrict__ lm, int64_t lm_stride, int64_t item,
-                                                   int compact, int split)
+                                                   int compact, int split, uint32_t* s_tile)
 {
     constexpr int NQ = T / 4 * 4; // dwords of own pixels per lane (4 cells * T px / 4)
     int r0, k, part = 0;
+    bool active = true; // strip mode: every thread of the workgroup reaches the barrier below
+    int tile_cb = 0, tile_gyb = 0, tile_ty = 0;
     if (compact == 2) {
-        // strip-interleaved plane: a wave = one strip (4 lanes x 4 cells) x 16 consecutive grid rows of one ty, so that
-        // each of its stores is one contiguous run of 256 bytes (16 strip rows of 16 bytes)
-        const int n_s = W >> 4, gyb_n = (H + 15) >> 4;
-        const int lane_in = (int)(item & 63);
-        const int64_t grp = item >> 6;
-        const int S = (int)(grp % n_s);
-        const int64_t rest = grp / n_s;
-        const int gyb = (int)(rest % gyb_n), ty_ = (int)(rest / gyb_n);
-        const int gy_ = gyb * 16 + (lane_in >> 2);
-        if (ty_ >= T || gy_ >= H) return;
-        r0 = gy_ * T + ty_;
-        k = S * 4 + (lane_in & 3);
+        // strip-interleaved plane: a WORKGROUP = one ty x 16 grid rows x 64 cells (4 strips).  Thread (row = t / 16,
+        // kk = t % 16) reads 4 cells of its row -- a wave's loads are 4 runs of 256 bytes -- and the spread dwords go
+        // through LDS so that wave w then stores strip w of the tile: 16 strip rows of 16 bytes = one run of 256 bytes
+        // per store.  (Round 2's first form let a wave own one strip end to end: contiguous stores, but each load
+        // gathered 64-byte pieces of 16 different rows; 14.9 us of the 16-frame launch were level 0.)
+        const int n_cb = (W + 63) >> 6, gyb_n = (H + 15) >> 4;
+        const int t = (int)(item & 255);
+        const int64_t blk = item >> 8;
+        tile_cb = (int)(blk % n_cb);
+        const int64_t rest = blk / n_cb;
+        tile_gyb = (int)(rest % gyb_n);
+        tile_ty = (int)(rest / gyb_n);
+        const int gy_ = tile_gyb * 16 + (t >> 4);
+        k = tile_cb * 16 + (t & 15);
+        active = tile_ty < T && gy_ < H && k * 4 < W;
+        r0 = active ? gy_ * T + tile_ty : 0;
+        if (!active) k = 0;
     } else {
         const int lanes_per_row = W >> 2;
         int64_t it = item;
@@ -906,7 +913,7 @@ __device__ __forceinline__ void build_lm_rows_item(const uint8_t* __restrict__ q
 #pragma unroll
     for (int d = 0; d < T; ++d) {
         const int r = r0 + d;
-        if (r < rows) {
+        if (r < rows && active) {
             const uint8_t* src = q + (size_t)r * cols + c0;
 #pragma unroll
             for (int i = 0; i < NQ; i += 4) {
@@ -949,15 +956,21 @@ __device__ __forceinline__ void build_lm_rows_item(const uint8_t* __restrict__ q
         const uint32_t p23 = perm_b32(d3, d2, 0x00000c0cu | ((4 + b) << 24) | (b << 16)); // {0, 0, d2.b, d3.b}
         return p01 | p23;
     };
-    if (compact) {
+    if (compact == 2) { // strip-interleaved spread plane (lm_strip_offset): a 16 x 16 patch is 2 - 4 cache lines
+        const int t = (int)(item & 255);
+        const int kk = t & 15, row = t >> 4;
 #pragma unroll
-        for (int tx = 0; tx < T; ++tx) {
-            const uint32_t sp = spread_dword(tx);
-            if (compact == 2) // strip-interleaved spread plane (lm_strip_offset): a 16 x 16 patch is 2 - 4 cache lines
-                *(uint32_t*)(lm + lm_strip_offset(ty * T + tx, gy, k * 4, W, H)) = sp;
-            else // one plane of spread bytes: the reader applies the response LUT for its own orientation
-                *(uint32_t*)(lm + (int64_t)(ty * T + tx) * WH + cell) = sp;
+        for (int tx = 0; tx < T; ++tx) s_tile[tx * 256 + (kk >> 2) * 64 + row * 4 + (kk & 3)] = spread_dword(tx);
+        __syncthreads();
+        const int S = tile_cb * 4 + (t >> 6), gy2 = tile_gyb * 16 + ((t & 63) >> 2);
+        if (tile_ty < T && S < (W >> 4) && gy2 < H) {
+#pragma unroll
+            for (int tx = 0; tx < T; ++tx)
+                *(uint32_t*)(lm + lm_strip_offset(tile_ty * T + tx, gy2, S * 16 + (t & 3) * 4, W, H)) = s_tile[tx * 256 + t];
         }
+    } else if (compact) { // one plane of spread bytes: the reader applies the response LUT for its own orientation
+#pragma unroll
+        for (int tx = 0; tx < T; ++tx) *(uint32_t*)(lm + (int64_t)(ty * T + tx) * WH + cell) = spread_dword(tx);
     } else {
         // 8 response planes: T * 8 dword stores per (row, 4 cells) -- 64 at T = 8, on a level with few rows.  For a
         // single frame (split > 1) the item is cut into LM_FULL_SPLIT parts (tx half = part >> 1, orientation half =
@@ -1011,6 +1024,7 @@ struct LmArgs {
 
 __global__ __launch_bounds__(256) void k_build_lm_rows(const LmArgs a)
 {
+    __shared__ uint32_t s_tile[8 * 256]; // strip levels: the workgroup's spread dwords, [tx][strip][row][4 cells]
     const size_t frame = blockIdx.y; // batch of frames: one grid row each
     if (blockIdx.x == 0 && a.counters) {
         if (threadIdx.x < 40) a.counters[frame * 40 + threadIdx.x] = 0;
@@ -1025,8 +1039,8 @@ __global__ __launch_bounds__(256) void k_build_lm_rows(const LmArgs a)
     const int64_t item = (int64_t)((int)blockIdx.x - p.block_begin) * 256 + threadIdx.x;
     const uint8_t* q = p.q + frame * p.q_fs;
     uint8_t* lm = p.lm + frame * p.lm_fs;
-    if (p.T == 4) build_lm_rows_item<4>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact, p.split);
-    else build_lm_rows_item<8>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact, p.split);
+    if (p.T == 4) build_lm_rows_item<4>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact, p.split, s_tile);
+    else build_lm_rows_item<8>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact, p.split, s_tile);
 }
 
 // compact plane (spread bytes) -> the 8 response planes, for the stage entry points that hand out or read a
