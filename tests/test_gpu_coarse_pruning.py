@@ -106,3 +106,40 @@ def test_batch_both_kernels_agree(oracle, forced_ctx, case1):
         for b in range(B):
             assert cnt[b, 1] == 0
             assert multiset(recs[b, : cnt[b, 0]]) == wants[b], (mode, b)
+
+
+@pytest.mark.parametrize("n_templates,B", [(7, 3), (121, 5), (358, 2)])
+def test_wave_kernel_ragged_template_count_and_batch(oracle, forced_ctx, case1, n_templates, B):
+    """one wave per item, four template slots per workgroup: template counts that are not multiples of 4, batches
+    without the frame -> XCD mapping (B not a multiple of 8), a frame geometry whose chunk count is not a multiple of 8"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    idx = sorted(set(np.linspace(0, 359, n_templates).astype(int).tolist()))  # spread over all rotations
+    if len(idx) % 4 == 0:
+        idx = idx[:-1]
+    ts = case1["templates"].subset(idx)
+    base = synth.embed(case1["test"], 576, 704, 20, 10)
+    frames = np.stack([np.roll(base, 24 * b, axis=1) for b in range(B)])
+    cap, rec = 4096, MATCH_DTYPE.itemsize
+    d_img = torch.from_numpy(frames).to(dev)
+    ctx = forced_ctx("wave")
+    ctx.upload_templates(ts)
+    stream = torch.cuda.Stream(device=dev)
+    d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(B * 2, dtype=torch.int32, device=dev)
+    ctx.match_batch_device(d_img.data_ptr(), frames[0].size, B, 576, 704, 704 * 3, 3, 85.0, d_out.data_ptr(), cap, d_cnt.data_ptr(),
+                           stream=stream.cuda_stream)
+    stream.synchronize()
+    cnt = d_cnt.cpu().numpy().reshape(B, 2)
+    recs = d_out.cpu().numpy().view(MATCH_DTYPE).reshape(B, cap)
+    total = 0
+    for b in range(B):
+        pyr = oracle.Pyramid.build(frames[b], [4, 8], 30.0)
+        want = multiset(pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 85.0, n_threads=min(16, os.cpu_count() or 1)))
+        pyr.free()
+        assert cnt[b, 1] == 0
+        assert multiset(recs[b, : cnt[b, 0]]) == want, (n_templates, b)
+        total += len(want)
+    assert total > 0 or n_templates < 20
+    assert ts.n_templates % 4 != 0
