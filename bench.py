@@ -242,7 +242,7 @@ def main():
                                     max_candidates=0 if wl.stage == "match" else 1 << 22)
             self.ctx.upload_templates(ts)
             self.ctx.select_range(first, count)
-            if os.environ.get("SBM_GRAPH"):
+            if os.environ.get("SBM_GRAPH", "0") not in ("", "0"):
                 self.ctx.set_graph_mode(True)
             if wl.maps is not None:
                 for l in range(len(T_LEVELS)):
@@ -327,6 +327,48 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         return el
+
+    # Launch configuration, chosen by measurement before the timed region.  The default -- stream launches, all slots
+    # round-robin -- is the fastest when nothing is wrong (6.98 us per frame against 7.23 with hipGraph replay and 10.4
+    # with one batch at a time).  One session in about forty on this pool ran the multi-slot stream path 2.6x slower
+    # with unchanged kernel times (launch / dispatch latency outside the engine); a 40-step probe of the alternatives
+    # the engine offers anyway (replay of the captured hipGraph: one host call per step; a single slot) costs a few
+    # milliseconds and keeps such a session from deciding the figure.
+    active = [slots]
+
+    def step():  # noqa: F811 -- the round-robin over the slots in use
+        a = active[0]
+        a[step_no[0] % len(a)].run()
+        step_no[0] += 1
+
+    def probe(n=40):
+        return timed(2 * len(active[0]), n) / n * 1e6
+
+    launch = {"path": "stream launches", "slots": len(slots)}
+    graph_env = os.environ.get("SBM_GRAPH", "0") not in ("", "0")
+    if graph_env:
+        launch["path"] = "hipGraph replay (SBM_GRAPH)"
+    elif wl.stage == "match" and B > 1 and not os.environ.get("SBM_BENCH_NO_ADAPT"):
+        t_stream = probe()
+        for sl in slots:
+            sl.ctx.set_graph_mode(True)
+        t_graph = probe()
+        launch["probe_us_per_step"] = {"stream launches": round(t_stream, 1), "hipGraph replay": round(t_graph, 1)}
+        if t_graph < 0.95 * t_stream:
+            launch["path"] = "hipGraph replay"
+        else:
+            for sl in slots:
+                sl.ctx.set_graph_mode(False)
+        if len(slots) > 1:
+            active[0] = slots[:1]
+            t_one = probe()
+            launch["probe_us_per_step"]["one slot"] = round(t_one, 1)
+            if t_one < 0.95 * min(t_stream, t_graph):
+                launch["slots"] = 1
+                if launch["path"] == "hipGraph replay":  # the single slot was probed with whichever path is now set
+                    pass
+            else:
+                active[0] = slots
 
     elapsed = timed(args.warmup, args.steps)
 
@@ -463,7 +505,8 @@ def main():
             "frames_per_step": frames_per_step_total,
             "frames_per_step_per_gpu": B,
             "us_per_frame": elapsed / args.steps / frames_per_step_total * 1e6,
-            "frames_in_flight": len(slots) * B,
+            "frames_in_flight": len(active[0]) * B,
+            "launch": launch,
             ("ms_per_step_one_frame_at_a_time" if B == 1 else "ms_per_step_one_batch_at_a_time"): single_ms,
             # SURVEY 8d's two times per frame, from the per-kernel pass (kernels alone on one stream):
             # t_match = all kernels, t_templ = the template loop (coarse + refinement) only

@@ -1314,9 +1314,11 @@ __device__ __forceinline__ void accumulate_features16(const uint8_t* __restrict_
     for (int b = 0; b < count; b += 64) {
         int sel = zero_off; // computed with every lane active: v_readlane below reads any lane's copy
         if (b + lane < count) {
+            // both loads issued together (a load of foff under the bounds test would wait for fxy first)
             const uint32_t xy = fxy[b + lane];
+            const int off = foff[b + lane];
             const int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
-            if (x < cols && y < rows) sel = foff[b + lane];
+            if (x < cols && y < rows) sel = off;
         }
         const int nb = count - b < 64 ? count - b : 64;
         // lanes past the template's span (lane_on == false) issue no loads at all; lane 63 fetches the
@@ -1403,9 +1405,11 @@ __device__ __forceinline__ bool accumulate_features16_pruned(const uint8_t* __re
     for (int b = 0; b < nf; b += 64) {
         int sel = zero_off;
         if (b + lane < nf) {
+            // both loads issued together (a load of foff under the bounds test would wait for fxy first)
             const uint32_t xy = fxy[b + lane];
+            const int off = foff[b + lane];
             const int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
-            if (x < cols && y < rows) sel = foff[b + lane];
+            if (x < cols && y < rows) sel = off;
         }
         const int nb = nf - b < 64 ? nf - b : 64;
         auto batch = [&](auto N, int u) {
@@ -1647,7 +1651,8 @@ __global__ __launch_bounds__(256) void k_similarity_coarse_wave(
     lm += (size_t)frame * lm_fs;
     cands += (size_t)frame * cap;
     counters += (size_t)frame * 40;
-    const int t = active[templ_slot];
+    // wave-uniform by construction: say so, and the template record and threshold come through the scalar cache
+    const int t = __builtin_amdgcn_readfirstlane(active[templ_slot]);
     const DevTL tl = tls[(size_t)t * L + lc];
     const int npos = template_positions(tl, W, H, T);
     const int rmin = raw_min[(size_t)t * L + lc];
