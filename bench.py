@@ -472,7 +472,8 @@ def main():
             "k_quantize": "vector-instruction issue (integer VALU at one wave-instruction per 4 cycles per SIMD); HBM traffic "
                           "equals the algorithmic bytes",
             "k_build_lm": "HBM writes of the linear memories",
-            "k_similarity_coarse": "L2 -> L1 bandwidth: the linear memories are re-read from the cache hierarchy by every template",
+            "k_similarity_coarse": "per-item latency chain + L2 -> L1 bandwidth of the items still alive (exact pruning: most of the "
+                                   "algorithmic bytes are never loaded)",
             "k_similarity_local": "L2 line traffic of the 16x16 patch reads + vector issue of the response LUT",
         }
         for name in kern:
