@@ -109,6 +109,7 @@ struct sbm_ctx {
     std::vector<int32_t> h_class, h_tid;
     std::vector<int32_t> h_active;
     DevBuf d_tls, d_fxy, d_flabel, d_flevel, d_foff, d_class, d_tid, d_active, d_rawmin, d_rawkeep;
+    DevBuf d_fxy_s, d_flabel_s, d_fcls; // refinement pass on the strip plane: features sorted by (x / T) & 15 per template level + 17 class offsets
     bool have_thr = false;
     float thr_cached = 0.f;
 
@@ -738,10 +739,12 @@ int enqueue_local(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap, 
         if (small_blocks) SBM_LOCAL_LW(COMPACT_, LM_, FS_, 4); else SBM_LOCAL_LW(COMPACT_, LM_, FS_, LOCAL_WAVES)
 #define SBM_LOCAL_LW(COMPACT_, LM_, FS_, LW_)                                                                                       \
         SBM_LAUNCH(c, "k_similarity_local", (k_similarity_local<COMPACT_, LW_>), dim3(frames, local_grid), dim3(64 * LW_), 0, s, LM_, \
-                   c->lm_stride[l], c->rows[l], c->cols[l], T, W, H, L, l, c->d_tls.as<DevTL>(), c->d_fxy.as<uint32_t>(),          \
+                   c->lm_stride[l], c->rows[l], c->cols[l], T, W, H, L, l, c->d_tls.as<DevTL>(),                                   \
+                   (COMPACT_) == 2 ? c->d_fxy_s.as<uint32_t>() : c->d_fxy.as<uint32_t>(),                                          \
                    c->d_foff.as<int32_t>(), c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),          \
                    c->d_cands.as<Cand>(), counters, (int)c->cand_cap, l == 0 ? 1 : 0, d_out, d_count, (int)cap, c->mirror_out,     \
-                   c->mirror_count, c->profiling ? 1 : 0, (int64_t)(FS_) * c->lm_stride[l], c->d_flabel.as<uint8_t>())
+                   c->mirror_count, c->profiling ? 1 : 0, (int64_t)(FS_) * c->lm_stride[l],                                        \
+                   (COMPACT_) == 2 ? c->d_flabel_s.as<uint8_t>() : c->d_flabel.as<uint8_t>(), c->d_fcls.as<uint16_t>())
         if (compact && c->lm_strip[l]) { SBM_LOCAL(2, c->d_lmc[l].as<uint8_t>(), 1); }
         else if (compact) { SBM_LOCAL(1, c->d_lmc[l].as<uint8_t>(), 1); }
         else { SBM_LOCAL(0, c->d_lm[l].as<uint8_t>(), 8); }
@@ -940,7 +943,7 @@ void sbm_destroy(sbm_ctx* c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side) (void)hipStreamDestroy(c->side);
     c->clear_timings();
-    DevBuf* singles[] = {&c->d_tls, &c->d_fxy, &c->d_flabel, &c->d_flevel, &c->d_foff, &c->d_class, &c->d_tid, &c->d_active,
+    DevBuf* singles[] = {&c->d_tls, &c->d_fxy, &c->d_flabel, &c->d_flevel, &c->d_foff, &c->d_class, &c->d_tid, &c->d_active, &c->d_fxy_s, &c->d_flabel_s, &c->d_fcls,
                          &c->d_rawmin, &c->d_rawkeep, &c->d_geo, &c->d_cands, &c->d_counters, &c->d_out, &c->d_outcount,
                          &c->d_scratch};
     for (DevBuf* b : singles) b->release();
@@ -988,6 +991,35 @@ int sbm_upload_templates(sbm_ctx* c, int32_t n_templates, const sbm_template_lev
             d.feat_off = (int32_t)s.feature_offset;
             tls[(size_t)t * L + l] = d;
         }
+    // class-sorted copies for the refinement pass on the strip-interleaved plane (accumulate_rows16_q): inside a
+    // template level the features are ordered by (x / T) & 15 (stable), fcls holds the 17 class offsets.  A sum does not
+    // care about the order of its terms; every other kernel keeps the caller's order.
+    std::vector<uint32_t> fxy_s(fxy);
+    std::vector<uint8_t> flabel_s(flabel);
+    std::vector<uint16_t> fcls((size_t)n_templates * L * 17, 0);
+    for (int t = 0; t < n_templates; ++t)
+        for (int l = 0; l < L; ++l) {
+            const DevTL& d = tls[(size_t)t * L + l];
+            const int T = c->cfg.T[l];
+            const int log2t = T == 4 ? 2 : (T == 8 ? 3 : -1);
+            uint16_t* cl = &fcls[((size_t)t * L + l) * 17];
+            if (log2t < 0) { // never read (the strip plane exists for T = 4 and 8 only)
+                for (int k = 1; k <= 16; ++k) cl[k] = (uint16_t)d.nf;
+                continue;
+            }
+            int cnt[17] = {0};
+            for (int i = 0; i < d.nf; ++i) ++cnt[(((fxy[d.feat_off + i] & 0xffff) >> log2t) & 15) + 1];
+            for (int k = 0; k < 16; ++k) cnt[k + 1] += cnt[k];
+            for (int k = 0; k <= 16; ++k) cl[k] = (uint16_t)cnt[k];
+            int pos[16];
+            for (int k = 0; k < 16; ++k) pos[k] = cnt[k];
+            for (int i = 0; i < d.nf; ++i) {
+                const int k = ((fxy[d.feat_off + i] & 0xffff) >> log2t) & 15;
+                fxy_s[d.feat_off + pos[k]] = fxy[d.feat_off + i];
+                flabel_s[d.feat_off + pos[k]] = flabel[d.feat_off + i];
+                ++pos[k];
+            }
+        }
     std::vector<int32_t> cls(n_templates), tid(n_templates);
     for (int t = 0; t < n_templates; ++t) {
         cls[t] = class_idx ? class_idx[t] : 0;
@@ -998,7 +1030,8 @@ int sbm_upload_templates(sbm_ctx* c, int32_t n_templates, const sbm_template_lev
     if ((rc = c->d_tls.ensure(tls.size() * sizeof(DevTL))) || (rc = c->d_fxy.ensure(fxy.size() * 4)) ||
         (rc = c->d_flabel.ensure(flabel.size())) || (rc = c->d_flevel.ensure(flevel.size())) ||
         (rc = c->d_foff.ensure(fxy.size() * 4)) || (rc = c->d_class.ensure(cls.size() * 4)) ||
-        (rc = c->d_tid.ensure(tid.size() * 4)))
+        (rc = c->d_tid.ensure(tid.size() * 4)) || (rc = c->d_fxy_s.ensure(fxy_s.size() * 4)) ||
+        (rc = c->d_flabel_s.ensure(flabel_s.size())) || (rc = c->d_fcls.ensure(std::max<size_t>(fcls.size(), 1) * 2)))
         return rc;
     HIP_TRY(hipDeviceSynchronize()); // frames still in flight on the caller's streams read the old tables
     if (!tls.empty()) HIP_TRY(hipMemcpy(c->d_tls.p, tls.data(), tls.size() * sizeof(DevTL), hipMemcpyHostToDevice));
@@ -1006,7 +1039,10 @@ int sbm_upload_templates(sbm_ctx* c, int32_t n_templates, const sbm_template_lev
         HIP_TRY(hipMemcpy(c->d_fxy.p, fxy.data(), fxy.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_flabel.p, flabel.data(), flabel.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_flevel.p, flevel.data(), flevel.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_fxy_s.p, fxy_s.data(), fxy_s.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_flabel_s.p, flabel_s.data(), flabel_s.size(), hipMemcpyHostToDevice));
     }
+    if (!fcls.empty()) HIP_TRY(hipMemcpy(c->d_fcls.p, fcls.data(), fcls.size() * 2, hipMemcpyHostToDevice));
     if (n_templates) {
         HIP_TRY(hipMemcpy(c->d_class.p, cls.data(), cls.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_tid.p, tid.data(), tid.size() * 4, hipMemcpyHostToDevice));

@@ -1752,6 +1752,122 @@ __device__ __forceinline__ void publish_counts(int32_t* __restrict__ counters, i
     }
 }
 
+// ---- refinement pass on the strip-interleaved plane: four features per wave instruction ----------------------
+// response4 with a per-lane orientation (the four 16-lane groups of a wave work on four different features)
+__device__ __forceinline__ uint32_t response4v(uint32_t v, uint32_t o, uint32_t o1, uint32_t o7)
+{
+    const uint32_t self = (v >> o) & 0x01010101u;
+    const uint32_t nb = ((v >> o1) | (v >> o7)) & (0x01010101u ^ self);
+    return (self << 2) | (nb * 3u);
+}
+
+struct __attribute__((aligned(16))) u128_a16 { uint32_t x, y, z, w; };
+
+// Lane = (feature slot g = lane >> 4, patch row r = lane & 15): a step of the wave adds FOUR features to the 16 x 16
+// patch; a lane loads the two aligned 16-byte strip rows that hold its row of the patch (strip s and s + 1: 32 bytes
+// of which the 16 starting at column c0 = gx0 & 15 are the patch row) and keeps 16 positions (4 packed dwords).
+// The dword misalignment Q = c0 >> 2 picks WHICH of the eight loaded dwords are used and must not cost a per-lane
+// select: the host sorts every template's features by (x / T) & 15, the class that fixes c0 for a given candidate
+// (c0 = (class + ox / T) & 15), and wave w of the workgroup takes the four (cyclically consecutive) classes whose Q
+// is w & 3 -- Q is a template parameter of the body.  Per feature that is 2 loads per FOUR features instead of 2 per
+// feature, no per-feature scalar address arithmetic, and ~15 vector instructions instead of ~25.
+// cls[0..16]: class start offsets inside the (sorted) feature range of this template level.
+// Result: lo[i] / hi[i] = packed u16 sums of columns 4i .. 4i+3 of row r, valid in lanes 0..15 of every wave
+// (the wave's share of the features), to be added over the workgroup's waves.
+template <int LOG2T, int Q, int NPARTS>
+__device__ __forceinline__ void accumulate_rows16_q(const uint8_t* __restrict__ lmc, const uint32_t* __restrict__ fxy,
+                                                    const uint8_t* __restrict__ flabel, const uint16_t* __restrict__ cls,
+                                                    int part, int rows, int cols, int ox, int oy, int W, int H,
+                                                    uint32_t (&lo)[4], uint32_t (&hi)[4])
+{
+    constexpr int T = 1 << LOG2T;
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, r = lane & 15;
+    const int X15 = (ox >> LOG2T) & 15;
+    const int k0 = (4 * Q - X15) & 15; // classes k0 .. k0+3 (mod 16) end up with dword misalignment Q
+    int a0 = cls[k0], a1, b1 = 0;      // up to two runs of the sorted list: [a0, a1) and [0, b1)
+    if (k0 <= 12) a1 = cls[k0 + 4];
+    else a1 = cls[16], b1 = cls[k0 - 12];
+    a0 = __builtin_amdgcn_readfirstlane(a0);
+    a1 = __builtin_amdgcn_readfirstlane(a1);
+    b1 = __builtin_amdgcn_readfirstlane(b1);
+    const int len1 = a1 - a0, n = len1 + b1;
+    const int per = ((((n + 3) >> 2) + NPARTS - 1) / NPARTS) << 2; // features per part (whole steps)
+    int j0 = per * part, j1 = j0 + per;
+    j0 = j0 < n ? j0 : n;
+    j1 = j1 < n ? j1 : n;
+    const uint32_t zero16 = (uint32_t)(((int64_t)T * T * W * H) >> 4); // the plane's zero tail (>= H*16 + 272 bytes)
+    const uint32_t pitch = (uint32_t)H * 16u;                         // strip s -> strip s + 1, same row
+    const uint32_t row_off = (uint32_t)r * 16u;
+    uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lo[i] = hi[i] = 0;
+    int pending = 0;
+    for (int jb = j0; jb < j1; jb += 64) {
+        // lane = feature: (strip row address / 16, column misalignment | label)
+        uint32_t recA = zero16, recB = 0;
+        const int jj = jb + lane;
+        if (jj < j1) {
+            const int idx = jj < len1 ? a0 + jj : jj - len1;
+            const uint32_t xy = fxy[idx];
+            const uint32_t lab = flabel[idx];
+            const int x = (int)(xy & 0xffff) + ox, y = (int)(xy >> 16) + oy;
+            const int gx0 = x >> LOG2T, gy0 = y >> LOG2T;
+            if (x >= 0 && y >= 0 && x < cols && y < rows)
+                recA = (uint32_t)(lm_strip_offset(((y & (T - 1)) << LOG2T) | (x & (T - 1)), gy0, gx0 & ~15, W, H) >> 4);
+            recB = (uint32_t)(gx0 & 3) | (lab << 2);
+        }
+        const int nbf = j1 - jb < 64 ? j1 - jb : 64;
+        auto batch = [&](auto N, int u) { // N steps = 4 N features, u = first feature of the batch (multiple of 4)
+            constexpr int nst = decltype(N)::value;
+            u128_a16 A[nst], B[nst];
+            uint32_t rb[nst];
+#pragma unroll
+            for (int k = 0; k < nst; ++k) {
+                const int f = (u + 4 * k + g) << 2; // lanes past the last feature hold the zero record
+                const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(f, (int)recA);
+                rb[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(f, (int)recB);
+                const uint8_t* p = lmc + ((size_t)a << 4) + row_off;
+                A[k] = *(const u128_a16*)p;
+                B[k] = *(const u128_a16*)(p + pitch);
+            }
+#pragma unroll
+            for (int k = 0; k < nst; ++k) {
+                const uint32_t sh = rb[k] & 3u, o = rb[k] >> 2, o1 = (o + 1u) & 7u, o7 = (o + 7u) & 7u;
+                const uint32_t d0 = Q == 0 ? A[k].x : Q == 1 ? A[k].y : Q == 2 ? A[k].z : A[k].w;
+                const uint32_t d1 = Q == 0 ? A[k].y : Q == 1 ? A[k].z : Q == 2 ? A[k].w : B[k].x;
+                const uint32_t d2 = Q == 0 ? A[k].z : Q == 1 ? A[k].w : Q == 2 ? B[k].x : B[k].y;
+                const uint32_t d3 = Q == 0 ? A[k].w : Q == 1 ? B[k].x : Q == 2 ? B[k].y : B[k].z;
+                const uint32_t d4 = Q == 0 ? B[k].x : Q == 1 ? B[k].y : Q == 2 ? B[k].z : B[k].w;
+                acc[0] += response4v(__builtin_amdgcn_alignbyte(d1, d0, sh), o, o1, o7);
+                acc[1] += response4v(__builtin_amdgcn_alignbyte(d2, d1, sh), o, o1, o7);
+                acc[2] += response4v(__builtin_amdgcn_alignbyte(d3, d2, sh), o, o1, o7);
+                acc[3] += response4v(__builtin_amdgcn_alignbyte(d4, d3, sh), o, o1, o7);
+            }
+            pending += nst;
+            if (pending + 4 > 63) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lo[i] += acc[i] & 0x00ff00ffu;
+                    hi[i] += (acc[i] >> 8) & 0x00ff00ffu;
+                    acc[i] = 0;
+                }
+                pending = 0;
+            }
+        };
+        int u = 0;
+        for (; u + 16 <= nbf; u += 16) batch(std::integral_constant<int, 4>{}, u);
+        if (nbf - u > 8) { batch(std::integral_constant<int, 2>{}, u); u += 8; }
+        if (nbf - u > 4) { batch(std::integral_constant<int, 2>{}, u); u += 8; }
+        else if (nbf - u > 0) batch(std::integral_constant<int, 1>{}, u);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lo[i] += acc[i] & 0x00ff00ffu;
+        hi[i] += (acc[i] >> 8) & 0x00ff00ffu;
+    }
+}
+
 // 16x16 patch of one candidate: lane = (row = lane>>2, 4 columns); the block's
 // LOCAL_WAVES waves each take a contiguous slice of the features and the partial
 // sums meet in LDS.  Result (packed u16) valid in wave 0.
@@ -1761,9 +1877,57 @@ __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int6
                                             const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
                                             int rows, int cols, int W, int H, int T, int ox, int oy,
                                             uint32_t (*s_part)[2][64], uint32_t& lo, uint32_t& hi,
-                                            const uint8_t* __restrict__ flabel = nullptr)
+                                            const uint8_t* __restrict__ flabel = nullptr,
+                                            const uint16_t* __restrict__ cls = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (COMPACT == 2) {
+        // strip plane: fxy / flabel are the class-sorted copies, cls the 17 class offsets of this template level;
+        // wave w takes the features whose dword misalignment is w & 3 (and, with 16 waves, a quarter of those)
+        static_assert(COMPACT != 2 || (LW & 3) == 0, "one wave (or LW / 4) per dword misalignment");
+        const int q = __builtin_amdgcn_readfirstlane(wave) & 3, part = __builtin_amdgcn_readfirstlane(wave) >> 2;
+        uint32_t l4[4], h4[4];
+        const uint32_t* fx = fxy + tl.feat_off;
+        const uint8_t* fl = flabel + tl.feat_off;
+#define SBM_ROWS16(LOG2T_)                                                                                              \
+        do {                                                                                                            \
+            if (q == 0) accumulate_rows16_q<LOG2T_, 0, LW / 4>(lm, fx, fl, cls, part, rows, cols, ox, oy, W, H, l4, h4);      \
+            else if (q == 1) accumulate_rows16_q<LOG2T_, 1, LW / 4>(lm, fx, fl, cls, part, rows, cols, ox, oy, W, H, l4, h4); \
+            else if (q == 2) accumulate_rows16_q<LOG2T_, 2, LW / 4>(lm, fx, fl, cls, part, rows, cols, ox, oy, W, H, l4, h4); \
+            else accumulate_rows16_q<LOG2T_, 3, LW / 4>(lm, fx, fl, cls, part, rows, cols, ox, oy, W, H, l4, h4);             \
+        } while (0)
+        if (T == 4) SBM_ROWS16(2);
+        else SBM_ROWS16(3);
+#undef SBM_ROWS16
+        // the four feature slots of the wave (lanes r, r+16, r+32, r+48), then the waves of the workgroup; the last
+        // read also turns (row, 16 columns) per lane into the (row, 4 columns) per lane the caller scans
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            l4[i] += (uint32_t)__shfl_xor((int)l4[i], 16, 64);
+            h4[i] += (uint32_t)__shfl_xor((int)h4[i], 16, 64);
+            l4[i] += (uint32_t)__shfl_xor((int)l4[i], 32, 64);
+            h4[i] += (uint32_t)__shfl_xor((int)h4[i], 32, 64);
+        }
+        uint32_t(*s8)[8][16] = (uint32_t(*)[8][16])s_part; // same bytes: [LW][2][64] == [LW][8][16]
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s8[wave][i][lane] = l4[i];
+                s8[wave][4 + i][lane] = h4[i];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            lo = hi = 0;
+#pragma unroll
+            for (int w = 0; w < LW; ++w) {
+                lo += s8[w][lane & 3][lane >> 2];
+                hi += s8[w][4 + (lane & 3)][lane >> 2];
+            }
+        }
+        __syncthreads();
+        return;
+    }
     const int r = lane >> 2, c4 = (lane & 3) * 4;
     const int delta = (oy / T) * W + ox / T + r * W + c4;
     const uint8_t* zero_addr = lm + (COMPACT ? 0 : 7) * lm_stride + (int64_t)T * T * W * H;
@@ -1771,13 +1935,8 @@ __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int6
     const int f0 = wave * chunk;
     int cnt = tl.nf - f0;
     cnt = cnt < 0 ? 0 : (cnt > chunk ? chunk : cnt);
-    if (COMPACT == 2) {
-        if (T == 4) accumulate_features_strip<2>(lm, fxy + tl.feat_off, flabel + tl.feat_off, f0, cnt, rows, cols, ox, oy, W, H, lo, hi);
-        else accumulate_features_strip<3>(lm, fxy + tl.feat_off, flabel + tl.feat_off, f0, cnt, rows, cols, ox, oy, W, H, lo, hi);
-    } else {
-        accumulate_features<COMPACT != 0>(lm, fxy + tl.feat_off, foff + tl.feat_off, f0, cnt, rows, cols, ox, oy, delta, zero_addr, 0, lo, hi,
-                                          COMPACT ? flabel + tl.feat_off : nullptr, (int)lm_stride);
-    }
+    accumulate_features<COMPACT != 0>(lm, fxy + tl.feat_off, foff + tl.feat_off, f0, cnt, rows, cols, ox, oy, delta, zero_addr, 0, lo, hi,
+                                      COMPACT ? flabel + tl.feat_off : nullptr, (int)lm_stride);
     s_part[wave][0][lane] = lo;
     s_part[wave][1][lane] = hi;
     __syncthreads();
@@ -1792,10 +1951,6 @@ __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int6
     __syncthreads();
 }
 
-// One block (LOCAL_WAVES waves) per candidate: refine at level l (line2Dup.cpp:1233-1287),
-// apply the per-level filter (:1290-1292); at level 0 emit the final Match record.
-// LW waves per candidate: 16 when a launch has few candidates per CU (their latency is the launch's duration), 4 for
-// a batch of frames (4x as many candidates in flight, idle slots 4x cheaper to dispatch).
 template <int COMPACT, int LW>
 __global__ __launch_bounds__(64 * LW) void k_similarity_local(
     const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int l,
@@ -1804,7 +1959,7 @@ __global__ __launch_bounds__(64 * LW) void k_similarity_local(
     const int32_t* __restrict__ template_id, Cand* __restrict__ cands, int32_t* __restrict__ counters,
     int cand_cap, int is_last, sbm_match_rec* __restrict__ out, int32_t* __restrict__ out_count,
     int out_cap, sbm_match_rec* __restrict__ mirror_out, int32_t* __restrict__ mirror_count, int collect_stats,
-    int64_t lm_fs, const uint8_t* __restrict__ flabel)
+    int64_t lm_fs, const uint8_t* __restrict__ flabel, const uint16_t* __restrict__ fcls)
 {
     // grid = (frames, candidate slots): the frame is the FAST grid dimension, so the blocks dispatched first are
     // the low slots of every frame -- the ones that have a candidate -- and the idle slots come last
@@ -1843,7 +1998,8 @@ __global__ __launch_bounds__(64 * LW) void k_similarity_local(
         y = y > max_y ? max_y : y;
         const int ox = (x / T - 8) * T, oy = (y / T - 8) * T;
         uint32_t lo, hi;
-        local_patch<COMPACT, LW>(lm, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi, flabel);
+        local_patch<COMPACT, LW>(lm, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi, flabel,
+                                 COMPACT == 2 ? fcls + ((size_t)c.t * L + l) * 17 : nullptr);
         if (wave != 0) continue;
         // first maximum in row-major order, strict '>' from 0 (:1265-1282): maximise (raw, -position)
         uint32_t best = 0;

@@ -98,6 +98,7 @@ def test_batch_both_kernels_agree(oracle, forced_ctx, case1):
         stream = torch.cuda.Stream(device=dev)
         d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)
         d_cnt = torch.zeros(B * 2, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()  # the fills run on torch's stream, the match on `stream`
         ctx.match_batch_device(d_img.data_ptr(), frames[0].size, B, 512, 640, 640 * 3, 3, 88.0, d_out.data_ptr(), cap, d_cnt.data_ptr(),
                                stream=stream.cuda_stream)
         stream.synchronize()
@@ -128,6 +129,7 @@ def test_wave_kernel_ragged_template_count_and_batch(oracle, forced_ctx, case1, 
     stream = torch.cuda.Stream(device=dev)
     d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)
     d_cnt = torch.zeros(B * 2, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()  # the fills run on torch's stream, the match on `stream`
     ctx.match_batch_device(d_img.data_ptr(), frames[0].size, B, 576, 704, 704 * 3, 3, 85.0, d_out.data_ptr(), cap, d_cnt.data_ptr(),
                            stream=stream.cuda_stream)
     stream.synchronize()

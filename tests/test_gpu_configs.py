@@ -81,6 +81,7 @@ def test_set_quantized_then_batch_at_new_geometry(oracle, ctx_factory, case1):
     frames = [big, np.ascontiguousarray(big[:, ::-1]), np.roll(big, 32, axis=1)]
     d_big = torch.from_numpy(np.stack(frames)).to(dev)
     d_cnt.fill_(-1)
+    torch.cuda.synchronize()  # uploads and fills ran on torch's stream, the match runs on `stream`
     ctx.match_batch_device(d_big.data_ptr(), big.size, B, 640, 768, 768 * 3, 3, 80.0, d_out.data_ptr(), cap, d_cnt.data_ptr(),
                            stream=stream.cuda_stream)
     stream.synchronize()

@@ -203,6 +203,7 @@ def test_match_batch_device(oracle, ctx_factory, case1, ch):
         for n, first in ((2, 0), (5, 0), (1, 2), (3, 2), (5, 0)):
             d_cnt.fill_(-1)
             h_cnt.fill_(-1)
+            torch.cuda.synchronize()  # fills on torch's stream, the match on `stream`
             ctx.match_batch_device(d_imgs.data_ptr() + first * fs, fs, n, rows, cols, cols * ch, ch, thr, d_out.data_ptr(), cap,
                                    d_cnt.data_ptr(), stream=stream.cuda_stream)
             stream.synchronize()
@@ -439,6 +440,7 @@ def test_match_batch_device_graph_replay(oracle, ctx_factory, case1):
 
     def run_and_check(order, mirror):
         d_cnt.fill_(-1)
+        torch.cuda.synchronize()  # the fill and the frame upload run on torch's stream, the match on `stream`
         ctx.match_batch_device(d_imgs.data_ptr(), fs, B, rows, cols, cols * 3, 3, thr, d_out.data_ptr(), cap, d_cnt.data_ptr(),
                                stream=stream.cuda_stream)
         stream.synchronize()

@@ -72,6 +72,7 @@ def test_stream_kernel_mask_and_batch(oracle, ctx_factory, case1):
         for mode in ("auto", "tile", "stream"):
             ctx.set_quantize_mode(mode)
             d_cnt.fill_(-1)
+            torch.cuda.synchronize()  # fill on torch's stream, the match on `stream`
             ctx.match_batch_device(d_imgs.data_ptr(), base.size, B, 640, 768, 768 * 3, 3, 80.0, d_out.data_ptr(), cap, d_cnt.data_ptr(),
                                    d_mask=d_mask.data_ptr() if use_mask else 0, stream=stream.cuda_stream)
             stream.synchronize()
