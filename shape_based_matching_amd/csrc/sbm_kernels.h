@@ -1211,77 +1211,6 @@ __device__ __forceinline__ void accumulate_features(const uint8_t* __restrict__ 
     hi += (acc >> 8) & 0x00ff00ffu;
 }
 
-// The refinement patch of one candidate from a STRIP-interleaved compact plane (lm_strip_offset): lane = (row r =
-// lane >> 2, column quarter lq = lane & 3) of the 16 x 16 patch.  Patch columns start at grid column gx0 (any
-// alignment): with q = (gx0 & 15) >> 2 and sh = gx0 & 3 the lane needs the two aligned dwords a = q + lq and a + 1
-// of the 32-byte run [strip S0 row | strip S0+1 row] and funnel-shifts them by sh bytes (v_alignbyte, wave-uniform
-// shift).  Per feature the wave touches 2 - 4 cache lines instead of 16.  Same calling convention as
-// accumulate_features (all 64 lanes active; out-of-image features read the plane's zero tail).
-template <int LOG2T>
-__device__ __forceinline__ void accumulate_features_strip(const uint8_t* __restrict__ lmc, const uint32_t* __restrict__ fxy,
-                                                          const uint8_t* __restrict__ flabel, int f0, int count, int rows,
-                                                          int cols, int ox, int oy, int W, int H, uint32_t& lo, uint32_t& hi)
-{
-    constexpr int T = 1 << LOG2T;
-    const int lane = threadIdx.x & 63;
-    const uint32_t lq = (uint32_t)lane & 3u;
-    const uint32_t p0 = (uint32_t)(lane >> 2) * 16u + lq * 4u; // byte offset of (row r, dword lq) inside a strip
-    const uint32_t wrap = (uint32_t)H * 16u - 16u;             // from the end of a strip row to the same row of the next strip
-    const uint32_t zero16 = (uint32_t)(((int64_t)T * T * W * H) >> 4); // the plane's zero tail (>= H*16 + 272 bytes, lm_stride_for)
-    uint32_t acc = 0;
-    lo = hi = 0;
-    int pending = 0;
-    count = __builtin_amdgcn_readfirstlane(count);
-    f0 = __builtin_amdgcn_readfirstlane(f0);
-    for (int b = 0; b < count; b += 64) {
-        // one record per feature: (byte offset of its strip row) / 16 in the high bits, q | sh << 2 | label << 4 below
-        uint32_t rec = zero16 << 7;
-        if (b + lane < count) {
-            const uint32_t xy = fxy[f0 + b + lane];
-            const int x = (int)(xy & 0xffff) + ox, y = (int)(xy >> 16) + oy;
-            const int gx0 = x >> LOG2T, gy0 = y >> LOG2T;
-            uint32_t base16 = zero16;
-            if (x >= 0 && y >= 0 && x < cols && y < rows)
-                base16 = (uint32_t)(lm_strip_offset(((y & (T - 1)) << LOG2T) | (x & (T - 1)), gy0, gx0 & ~15, W, H) >> 4);
-            rec = (base16 << 7) | (uint32_t)(((gx0 & 15) >> 2) | ((gx0 & 3) << 2)) | ((uint32_t)flabel[f0 + b + lane] << 4);
-        }
-        const int nb = count - b < 64 ? count - b : 64;
-        auto batch = [&](auto N, int u) {
-            constexpr int n = decltype(N)::value;
-            uint32_t d0[n], d1[n];
-            uint32_t pr[n];
-#pragma unroll
-            for (int k = 0; k < n; ++k) {
-                pr[k] = (uint32_t)__builtin_amdgcn_readlane((int)rec, (u + k) & 63);
-                const uint8_t* p = lmc + ((size_t)(pr[k] >> 7) << 4) + ((pr[k] & 3u) << 2); // + q dwords
-                const uint32_t t = (pr[k] & 3u) + lq;                                      // dword index a = q + lq in 0 .. 6
-                // 32-bit offsets (v_mad_u32_u24: the 64-bit multiply-add the pointer arithmetic would otherwise become
-                // issues at a quarter of the rate)
-                const uint32_t off0 = __umul24(t >> 2, wrap) + p0, off1 = __umul24((t + 1) >> 2, wrap) + p0;
-                d0[k] = *(const uint32_t*)(p + off0);
-                d1[k] = *(const uint32_t*)(p + off1 + 4);
-            }
-#pragma unroll
-            for (int k = 0; k < n; ++k)
-                acc += response4(__builtin_amdgcn_alignbyte(d1[k], d0[k], (pr[k] >> 2) & 3u), (int)((pr[k] >> 4) & 7u));
-            pending += n;
-            if (pending + FBL > 63) {
-                lo += acc & 0x00ff00ffu;
-                hi += (acc >> 8) & 0x00ff00ffu;
-                acc = 0;
-                pending = 0;
-            }
-        };
-        int u = 0;
-        for (; u + FBL <= nb; u += FBL) batch(std::integral_constant<int, FBL>{}, u);
-        if (FBL > 8 && nb - u >= 8) { batch(std::integral_constant<int, 8>{}, u); u += 8; }
-        if (nb - u >= 4) { batch(std::integral_constant<int, 4>{}, u); u += 4; }
-        if (nb - u >= 2) { batch(std::integral_constant<int, 2>{}, u); u += 2; }
-        if (nb - u >= 1) batch(std::integral_constant<int, 1>{}, u);
-    }
-    lo += acc & 0x00ff00ffu;
-    hi += (acc >> 8) & 0x00ff00ffu;
-}
 
 __device__ __forceinline__ int unpack4(uint32_t lo, uint32_t hi, int k)
 {
