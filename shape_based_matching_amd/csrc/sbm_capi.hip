@@ -364,6 +364,13 @@ int upload_geo(sbm_ctx* c, hipStream_t s)
 // frame would be a few long serial chains; the tile kernel (k_quantize) is the latency form (1024 short-lived tiles
 // per Mpixel) and the only one with the float outputs and arbitrary widths.  SBM_QUANTIZE=tile|stream forces one for
 // A/B runs, SBM_QS_HS sets the rows per wave.
+// segment lanes of the packed last strip (0: none); SBM_QS_PACK=0 is the A/B knob
+static int qs_pack_lanes(int rows, int cols, int ch, int frames)
+{
+    static const bool pack_ok = !(getenv("SBM_QS_PACK") && atoi(getenv("SBM_QS_PACK")) == 0);
+    return pack_ok ? quantize_stream_pack_lanes(rows, cols, ch, frames) : 0;
+}
+
 int quantize_stream_rows(const sbm_ctx* c, int rows, int cols, int ch, int frames, bool wf)
 {
     static const char* env = getenv("SBM_QUANTIZE");
@@ -377,10 +384,13 @@ int quantize_stream_rows(const sbm_ctx* c, int rows, int cols, int ch, int frame
     // BGR kernel's register count, 6 for gray) to hide the scalar bookkeeping and dependency bubbles of each: a launch
     // takes about  ceil(waves / resident slots) x (hs + 10 halo rows).  Choose the rows per wave that minimise it.
     const int64_t slots = 1024 * (ch == 3 ? 3 : 6);
+    // waves per row block: one per strip and frame, except that a narrow last strip is shared by several frames
+    const int pack = qs_pack_lanes(rows, cols, ch, frames);
+    const int64_t per_rb = pack ? (strips - 1) * frames + (frames + 64 / pack - 1) / (64 / pack) : strips * frames;
     int hs = 0;
     int64_t best = INT64_MAX;
-    for (int h = 8; h <= 128; h += 2) {
-        const int64_t waves = strips * ((rows + h - 1) / h) * frames;
+    for (int h = 6; h <= 128; h += 2) {
+        const int64_t waves = per_rb * ((rows + h - 1) / h);
         const int64_t cost = ((waves + slots - 1) / slots) * (std::min(h, rows) + 10);
         if (cost <= best) best = cost, hs = h;
     }
@@ -414,7 +424,10 @@ int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, i
         a.hs = hs;
         a.n_strips = (cols + QS_USEFUL - 1) / QS_USEFUL;
         a.n_rblocks = (rows + hs - 1) / hs;
-        const dim3 g((unsigned)((a.n_strips * a.n_rblocks + 3) / 4), (unsigned)frames);
+        a.frames = frames;
+        a.pack_lanes = qs_pack_lanes(rows, cols, ch, frames);
+        a.pack_groups = a.pack_lanes ? (frames + 64 / a.pack_lanes - 1) / (64 / a.pack_lanes) : 0;
+        const dim3 g((unsigned)((quantize_stream_items(a) + 3) / 4));
         // experiment knob: dynamic LDS the kernel never touches, to cap the workgroups per CU (waves per SIMD)
         static const int lds_pad = getenv("SBM_QS_LDS") ? atoi(getenv("SBM_QS_LDS")) : 0;
         if (lds_pad > 0) {

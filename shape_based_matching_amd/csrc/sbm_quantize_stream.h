@@ -58,6 +58,13 @@ struct QSArgs {
     int32_t thr_i;       // floor(weak^2): `mag > weak^2` in integers
     int32_t hs;          // output rows per work item (even)
     int32_t n_strips, n_rblocks;
+    int32_t frames;      // frames of the batch
+    // Packed last strip.  The last strip of a row covers cols - 240 (n_strips - 1) columns -- 64 of 1024, 32 of 512 --
+    // and a wave of its own would leave most lanes idle.  With pack_lanes > 0 a wave takes that strip of up to
+    // 64 / pack_lanes FRAMES side by side: segment g of pack_lanes lanes (2 halo + useful + 2 halo) is frame f0 + g.
+    // Same rows, same columns, so every scalar decision of the row loop is unchanged; only the per-lane column and
+    // the per-lane frame offset of loads and stores differ.  pack_groups = frame groups per row block.
+    int32_t pack_lanes, pack_groups;
 };
 
 // Gaussian / pyrDown weights as packed pairs (lo | hi << 16)
@@ -94,8 +101,9 @@ __device__ __forceinline__ wv::V qs_vote_word(wv::V v)
 }
 
 // One work item: strip `strip`, output rows [rb*hs, min(rb*hs+hs, rows)), frame `frame`.
+// nseg == 0: the whole wave is strip `strip` of frame `frame`; nseg > 0: packed last strip of frames frame .. frame+nseg-1
 template <int CH>
-__device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip, int rb, int frame)
+__device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip, int rb, int frame, int nseg = 0)
 {
     using namespace wv;
     constexpr int ND = CH == 3 ? 3 : 1; // source dwords per lane and row
@@ -110,12 +118,20 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
 
     // ---- per-lane constants ----
     const V lane = lane_id();
-    const V c0 = splat((uint32_t)cb) + (lane << 2);       // first column of this lane (may be negative / >= cols)
+    V lseg = lane, segv = splat(0u); // lane inside its segment, segment (= frame - `frame`) of the lane
+    const uint32_t seg_lanes = nseg ? (uint32_t)a.pack_lanes : 64u;
+    if (nseg) {
+        for (uint32_t k = 1; k * seg_lanes < 64u; ++k) segv = segv + select(ge_i(lane, splat(k * seg_lanes)), 1u, 0u);
+        lseg = lane - segv * seg_lanes;
+    }
+    const P seg_ok = lt_i(segv, splat(nseg ? (uint32_t)nseg : 1u)); // lanes past the last frame of the group idle
+    const V segc = select(seg_ok, segv, 0u);
+    const V c0 = splat((uint32_t)cb) + (lseg << 2);       // first column of this lane (may be negative / >= cols)
     const V lcol = clamp_i(c0, 0, cols - 4);              // column actually loaded (BORDER_REPLICATE)
-    const V ld_off = CH == 3 ? lcol + (lcol << 1) : lcol; // byte offset in the source row
+    const V ld_off = (CH == 3 ? lcol + (lcol << 1) : lcol) + segc * (uint32_t)a.img_fs; // byte offset from the frame's source row
     const P left_out = lt_i(c0, splat(0u)), right_out = ge_i(c0, splat((uint32_t)cols));
     const P outside = p_or(left_out, right_out);
-    const bool border_strip = cb < 0 || cb + 256 > cols;  // some lane replicates the first / last pixel
+    const bool border_strip = nseg || cb < 0 || cb + 256 > cols; // some lane replicates the first / last pixel
     // pixels allowed to be non-zero / to carry a real vote: columns 1 .. cols-2 (ring and outside vote for bin 0)
     V cm[4];
     P real_col[4];
@@ -125,13 +141,17 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
         real_col[j] = p_and(gt_i(c, splat(0u)), lt_i(c, splat((uint32_t)(cols - 1))));
         cm[j] = select(real_col[j], 0x88888888u, 0u);
     }
-    const P store_ok = p_and(p_and(ge_i(lane, splat((uint32_t)QS_HALO_LANES)), lt_i(lane, splat((uint32_t)(64 - QS_HALO_LANES)))),
-                             p_and(ge_i(c0, splat(0u)), lt_i(c0, splat((uint32_t)cols))));
-    // lanes that own no output (halo, past the right border) carry an offset the buffer range check discards
-    const Buf out_buf = make_buf(out, (uint32_t)rows * (uint32_t)cols);
-    const Buf pyr_buf = make_buf(pyr, pyr ? (uint32_t)drows * (uint32_t)dcols * CH : 0u);
-    const V out_off = select(store_ok, c0, BUF_DROP);                                              // + yv * cols
-    const V pyr_off = select(store_ok, CH == 3 ? (c0 >> 1) + ((c0 >> 1) << 1) : (c0 >> 1), BUF_DROP); // (c0 / 2) * CH
+    const P store_ok = p_and(p_and(p_and(ge_i(lseg, splat((uint32_t)QS_HALO_LANES)), lt_i(lseg, splat(seg_lanes - QS_HALO_LANES))),
+                                   p_and(ge_i(c0, splat(0u)), lt_i(c0, splat((uint32_t)cols)))),
+                             seg_ok);
+    // lanes that own no output (halo, past the right border, no frame) carry an offset the buffer range check discards;
+    // a packed wave's buffers span its nseg frames (out_fs, pyr_fs: one frame's bytes)
+    const uint32_t nfr = nseg ? (uint32_t)nseg : 1u;
+    const Buf out_buf = make_buf(out, nseg ? nfr * (uint32_t)a.out_fs : (uint32_t)rows * (uint32_t)cols);
+    const Buf pyr_buf = make_buf(pyr, pyr ? (nseg ? nfr * (uint32_t)a.pyr_fs : (uint32_t)drows * (uint32_t)dcols * CH) : 0u);
+    const V out_off = select(store_ok, c0 + segc * (uint32_t)a.out_fs, BUF_DROP);                  // + yv * cols
+    const V pyr_off = select(store_ok, (CH == 3 ? (c0 >> 1) + ((c0 >> 1) << 1) : (c0 >> 1)) + segc * (uint32_t)a.pyr_fs,
+                             BUF_DROP);                                                           // (c0 / 2) * CH
     // border lanes: byte selectors that turn the loaded (clamped) group into 4 copies of its first / last pixel
     V selA = splat(0x03020100u), selB = splat(0x03020100u), selC = splat(0x07060504u);
     if (CH == 3) {
@@ -450,16 +470,51 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
     }
 }
 
+// Work items of a launch: (strip, row block, frame) for the strips that get a wave per frame, then (row block, frame
+// group) for a packed last strip.
+__host__ __device__ inline int quantize_stream_items(const QSArgs& a)
+{
+    const int n_full = a.pack_lanes ? a.n_strips - 1 : a.n_strips;
+    return n_full * a.n_rblocks * a.frames + (a.pack_lanes ? a.n_rblocks * a.pack_groups : 0);
+}
+
+template <int CH>
+__device__ __forceinline__ void quantize_stream_item(const QSArgs& a, int item)
+{
+    const int n_full = a.pack_lanes ? a.n_strips - 1 : a.n_strips; // strips that get a wave per frame
+    const int per_frame = n_full * a.n_rblocks, n_plain = per_frame * a.frames;
+    if (item < n_plain) {
+        const int frame = item / per_frame, r = item - frame * per_frame;
+        quantize_stream_wave<CH>(a, r % n_full, r / n_full, frame, 0);
+    } else {
+        const int j = item - n_plain;
+        if (!a.pack_lanes || j >= a.n_rblocks * a.pack_groups) return;
+        const int grp = j / a.n_rblocks, per = 64 / a.pack_lanes, f0 = grp * per;
+        const int nseg = a.frames - f0 < per ? a.frames - f0 : per;
+        quantize_stream_wave<CH>(a, a.n_strips - 1, j - grp * a.n_rblocks, f0, nseg);
+    }
+}
+
+// segment lanes of a packed last strip for this geometry, 0 = the last strip gets a wave per frame like the others
+__host__ __device__ inline int quantize_stream_pack_lanes(int rows, int cols, int ch, int frames)
+{
+    const int n_strips = (cols + QS_USEFUL - 1) / QS_USEFUL;
+    const int lanes = (cols - QS_USEFUL * (n_strips - 1)) / QS_LANE_PX + 2 * QS_HALO_LANES;
+    const int per = 64 / lanes;
+    // per-lane offsets are 32-bit: the frames of a group must lie within 2 GiB of the first
+    if (frames < 2 || per < 2 || (long long)per * rows * cols * ch >= 0x7ff00000ll) return 0;
+    return lanes;
+}
+
 #ifndef SBM_WAVE_EMU
-// grid = (ceil(n_strips * n_rblocks / 4), frames), block = 256 = four independent waves
+// grid = ceil(work items / 4), block = 256 = four independent waves
 template <int CH>
 __global__ __launch_bounds__(256) void k_quantize_stream(const QSArgs a)
 {
     // the wave index is the same in all 64 lanes: tell the compiler, so that everything derived from the work item
     // (row counters, stage gating, row base addresses) lives in SGPRs and branches are scalar
     const int item = (int)blockIdx.x * 4 + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (item >= a.n_strips * a.n_rblocks) return;
-    quantize_stream_wave<CH>(a, item % a.n_strips, item / a.n_strips, (int)blockIdx.y);
+    quantize_stream_item<CH>(a, item);
 }
 #endif
 

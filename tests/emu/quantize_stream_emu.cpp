@@ -24,10 +24,42 @@ extern "C" int sbm_emu_quantize_stream(const uint8_t* img, int rows, int cols, i
     a.hs = hs;
     a.n_strips = (cols + sbm::QS_USEFUL - 1) / sbm::QS_USEFUL;
     a.n_rblocks = (rows + hs - 1) / hs;
-    for (int rb = 0; rb < a.n_rblocks; ++rb)
-        for (int s = 0; s < a.n_strips; ++s) {
-            if (ch == 3) sbm::quantize_stream_wave<3>(a, s, rb, 0);
-            else sbm::quantize_stream_wave<1>(a, s, rb, 0);
-        }
+    a.frames = 1;
+    for (int item = 0; item < sbm::quantize_stream_items(a); ++item) {
+        if (ch == 3) sbm::quantize_stream_item<3>(a, item);
+        else sbm::quantize_stream_item<1>(a, item);
+    }
     return 0;
+}
+
+// a batch of `frames` contiguous frames, the way the engine launches it: with pack != 0 the last strip of up to
+// 64 / pack_lanes frames shares a wave (quantize_stream_pack_lanes decides, as on the GPU)
+extern "C" int sbm_emu_quantize_stream_batch(const uint8_t* img, int frames, int rows, int cols, int stride, int ch, const uint8_t* mask,
+                                             float weak, uint8_t* out, uint8_t* pyr, int hs, int pack)
+{
+    if ((ch != 1 && ch != 3) || cols < 4 || (cols & 3) || rows < 1 || hs < 2 || (hs & 1) || frames < 1) return -1;
+    sbm::QSArgs a{};
+    a.img = img;
+    a.mask = mask;
+    a.out = out;
+    a.pyr = pyr;
+    a.img_fs = (int64_t)rows * stride;
+    a.out_fs = (int64_t)rows * cols;
+    a.pyr_fs = (int64_t)(rows / 2) * (cols / 2) * ch;
+    a.rows = rows;
+    a.cols = cols;
+    a.stride = stride;
+    const float thr_sq = weak * weak;
+    a.thr_i = thr_sq < 2147483000.f ? (int)floorf(thr_sq) : INT_MAX;
+    a.hs = hs;
+    a.n_strips = (cols + sbm::QS_USEFUL - 1) / sbm::QS_USEFUL;
+    a.n_rblocks = (rows + hs - 1) / hs;
+    a.frames = frames;
+    a.pack_lanes = pack ? sbm::quantize_stream_pack_lanes(rows, cols, ch, frames) : 0;
+    a.pack_groups = a.pack_lanes ? (frames + 64 / a.pack_lanes - 1) / (64 / a.pack_lanes) : 0;
+    for (int item = 0; item < sbm::quantize_stream_items(a); ++item) {
+        if (ch == 3) sbm::quantize_stream_item<3>(a, item);
+        else sbm::quantize_stream_item<1>(a, item);
+    }
+    return a.pack_lanes;
 }

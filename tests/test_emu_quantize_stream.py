@@ -23,6 +23,7 @@ def emu():
     L = C.CDLL(os.path.join(EMU_DIR, "libsbm_emu.so"))
     vp = C.c_void_p
     L.sbm_emu_quantize_stream.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp, C.c_int]
+    L.sbm_emu_quantize_stream_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp, C.c_int, C.c_int]
 
     def run(img, weak=30.0, hs=32, mask=None):
         img = np.ascontiguousarray(img)
@@ -35,6 +36,18 @@ def emu():
         assert rc == 0
         return out, pyr
 
+    def run_batch(frames, weak=30.0, hs=32, mask=None, pack=1):
+        frames = np.ascontiguousarray(frames)
+        n, r, c = frames.shape[:3]
+        ch = 1 if frames.ndim == 3 else 3
+        out = np.full((n, r, c), 0xAA, np.uint8)
+        pyr = np.full((n, r // 2, c // 2) + (() if ch == 1 else (3,)), 0xAA, np.uint8)
+        lanes = L.sbm_emu_quantize_stream_batch(frames.ctypes.data, n, r, c, c * ch, ch, None if mask is None else mask.ctypes.data,
+                                                weak, out.ctypes.data, pyr.ctypes.data, hs, pack)
+        assert lanes >= 0
+        return out, pyr, lanes
+
+    run.batch = run_batch
     return run
 
 
@@ -122,3 +135,45 @@ def test_constant_run_fast_forward_chunks(emu, oracle, ch):
         img[120:] = 200  # a second colour: a new run after one changing row
         for hs in (32, 64, 140):
             check(emu, oracle, img, hs=hs)
+
+
+def check_batch(emu, oracle, frames, expect_lanes, weak=30.0, hs=16, mask=None):
+    out, pyr, lanes = emu.batch(frames, weak, hs, mask, pack=1)
+    assert lanes == expect_lanes
+    for f in range(frames.shape[0]):
+        _, ang, _ = oracle.quantized_orientations(frames[f], weak)
+        if mask is not None:
+            ang = np.where(mask != 0, ang, 0).astype(np.uint8)
+        assert np.array_equal(out[f], ang), (f, np.argwhere(out[f] != ang)[:5])
+        assert np.array_equal(pyr[f], oracle.pyrdown(frames[f])), f
+    # the unpacked launch of the same batch gives the same bytes
+    out1, pyr1, lanes1 = emu.batch(frames, weak, hs, mask, pack=0)
+    assert lanes1 == 0 and np.array_equal(out1, out) and np.array_equal(pyr1, pyr)
+
+
+def test_packed_last_strip_of_several_frames(emu, oracle, case1):
+    """the last strip of a row (cols - 240 k columns) of up to 64 / (useful lanes + 4) frames shares one wave:
+    different frames side by side, each with its own halo lanes, borders, constant runs and pyrDown"""
+    rs = np.random.RandomState(11)
+    # 272 columns = 240 + 32: last strip 8 useful + 4 halo lanes = 12 -> 5 frames per wave; 7 frames = groups of 5 + 2
+    fr = np.stack([synth.scene_bgr(40 + i, 60, 272) for i in range(7)])
+    fr[3, :, 200:] = (9, 9, 9)  # a constant right part in one frame only: the wave must not take the shortcut
+    fr[5] = 77                  # a completely constant frame next to textured ones
+    check_batch(emu, oracle, fr, 12)
+    # gray, 304 columns: 64 + 4*... last strip 64 px = 16 + 4 lanes = 20 -> 3 frames per wave; 4 frames
+    g = np.stack([rs.randint(0, 256, (40, 304)).astype(np.uint8) for _ in range(4)])
+    check_batch(emu, oracle, g, 20, hs=8)
+    # one strip only (the strip is first and last: both image borders inside the segments), odd row count, mask
+    small = np.stack([synth.scene_bgr(70 + i, 37, 40) for i in range(6)])
+    m = np.zeros((37, 40), np.uint8)
+    m[5:30, 3:33] = 255
+    check_batch(emu, oracle, small, 14, hs=6, mask=m)
+    # all frames constant and equal: the packed wave takes the constant-row shortcut
+    flat = np.full((5, 48, 272, 3), 31, np.uint8)
+    check_batch(emu, oracle, flat, 12)
+    # a last strip too wide to share a wave (200 of 240 columns useful): falls back to a wave per frame
+    wide = np.stack([synth.scene_gray(90 + i, 32, 440) for i in range(3)])
+    out, pyr, lanes = emu.batch(wide, 30.0, 16, None, pack=1)
+    assert lanes == 0
+    for f in range(3):
+        assert np.array_equal(out[f], oracle.quantized_orientations(wide[f], 30.0)[1])
