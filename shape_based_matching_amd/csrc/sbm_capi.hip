@@ -383,7 +383,10 @@ int quantize_stream_rows(const sbm_ctx* c, int rows, int cols, int ch, int frame
     // The kernel is bound by vector-instruction issue, and a SIMD needs its full set of resident waves (3 at the
     // BGR kernel's register count, 6 for gray) to hide the scalar bookkeeping and dependency bubbles of each: a launch
     // takes about  ceil(waves / resident slots) x (hs + 10 halo rows).  Choose the rows per wave that minimise it.
-    const int64_t slots = 1024 * (ch == 3 ? 3 : 6);
+    // resident waves per SIMD the launch is sized for (experiment knob SBM_QS_WAVES, with SBM_QS_LDS capping the
+    // workgroups per CU to match: fewer gradient waves leave registers for the other kernels' waves)
+    static const int env_w = getenv("SBM_QS_WAVES") ? atoi(getenv("SBM_QS_WAVES")) : 0;
+    const int64_t slots = 1024 * (env_w > 0 ? env_w : (ch == 3 ? 3 : 6));
     // waves per row block: one per strip and frame, except that a narrow last strip is shared by several frames
     const int pack = qs_pack_lanes(rows, cols, ch, frames);
     const int64_t per_rb = pack ? (strips - 1) * frames + (frames + 64 / pack - 1) / (64 / pack) : strips * frames;
