@@ -365,13 +365,19 @@ int upload_geo(sbm_ctx* c, hipStream_t s)
 // per Mpixel) and the only one with the float outputs and arbitrary widths.  SBM_QUANTIZE=tile|stream forces one for
 // A/B runs, SBM_QS_HS sets the rows per wave.
 // segment lanes of the packed last strip (0: none); SBM_QS_PACK=0 is the A/B knob
-static int qs_pack_lanes(int rows, int cols, int ch, int frames)
+static int qs_pack_lanes(int rows, int cols, int ch, int frames, int64_t img_fs, int stride)
 {
     static const bool pack_ok = !(getenv("SBM_QS_PACK") && atoi(getenv("SBM_QS_PACK")) == 0);
-    return pack_ok ? quantize_stream_pack_lanes(rows, cols, ch, frames) : 0;
+    const int lanes = pack_ok ? quantize_stream_pack_lanes(rows, cols, ch, frames) : 0;
+    if (!lanes) return 0;
+    // the frames of a group are addressed by 32-bit per-lane offsets from the group's first frame: the caller's frame
+    // stride (any value, also negative or zero) must keep them within 2 GiB
+    const int64_t span = (int64_t)(64 / lanes - 1) * img_fs;
+    if (img_fs < 0 || span + (int64_t)rows * stride >= (int64_t)0x7ff00000) return 0;
+    return lanes;
 }
 
-int quantize_stream_rows(const sbm_ctx* c, int rows, int cols, int ch, int frames, bool wf)
+int quantize_stream_rows(const sbm_ctx* c, int rows, int cols, int ch, int frames, bool wf, int64_t img_fs, int stride)
 {
     static const char* env = getenv("SBM_QUANTIZE");
     static const int env_hs = getenv("SBM_QS_HS") ? atoi(getenv("SBM_QS_HS")) : 0;
@@ -388,7 +394,7 @@ int quantize_stream_rows(const sbm_ctx* c, int rows, int cols, int ch, int frame
     static const int env_w = getenv("SBM_QS_WAVES") ? atoi(getenv("SBM_QS_WAVES")) : 0;
     const int64_t slots = 1024 * (env_w > 0 ? env_w : (ch == 3 ? 3 : 6));
     // waves per row block: one per strip and frame, except that a narrow last strip is shared by several frames
-    const int pack = qs_pack_lanes(rows, cols, ch, frames);
+    const int pack = qs_pack_lanes(rows, cols, ch, frames, img_fs, stride);
     const int64_t per_rb = pack ? (strips - 1) * frames + (frames + 64 / pack - 1) / (64 / pack) : strips * frames;
     int hs = 0;
     int64_t best = INT64_MAX;
@@ -410,7 +416,7 @@ int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, i
     const float thr_sq = weak * weak;
     const bool wf = d_mag || d_ori;
     const int64_t out_fs = (int64_t)rows * cols, pyr_fs = (int64_t)(rows / 2) * (cols / 2) * ch; // the context's own per-frame buffers
-    if (const int hs = quantize_stream_rows(c, rows, cols, ch, frames, wf)) {
+    if (const int hs = quantize_stream_rows(c, rows, cols, ch, frames, wf, img_fs, stride)) {
         QSArgs a;
         memset(&a, 0, sizeof a);
         a.img = d_img;
@@ -428,7 +434,7 @@ int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, i
         a.n_strips = (cols + QS_USEFUL - 1) / QS_USEFUL;
         a.n_rblocks = (rows + hs - 1) / hs;
         a.frames = frames;
-        a.pack_lanes = qs_pack_lanes(rows, cols, ch, frames);
+        a.pack_lanes = qs_pack_lanes(rows, cols, ch, frames, img_fs, stride);
         a.pack_groups = a.pack_lanes ? (frames + 64 / a.pack_lanes - 1) / (64 / a.pack_lanes) : 0;
         const dim3 g((unsigned)((quantize_stream_items(a) + 3) / 4));
         // experiment knob: dynamic LDS the kernel never touches, to cap the workgroups per CU (waves per SIMD)
