@@ -84,3 +84,43 @@ def test_stream_kernel_mask_and_batch(oracle, ctx_factory, case1):
                 p.free()
                 assert cnt[f, 1] == 0 and cnt[f, 0] == len(want), (use_mask, mode, f)
                 assert key(out[f].view(MATCH_DTYPE)[: cnt[f, 0]]) == key(want), (use_mask, mode, f)
+
+
+def test_stream_kernel_packed_strip_with_frame_stride(oracle, ctx_factory, case1):
+    """the narrow last strip of several frames shares a wave (768 columns: 3 x 240 + 48 -> 4 frames per wave), also when
+    the caller's frames are not contiguous (every other frame of a buffer: frame stride = 2 frames) and when the batch
+    is not a multiple of the group size; every frame's orientation map and match list against the oracle"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    ts = case1["templates"].subset(range(300, 361, 6))
+    base = synth.embed(case1["test"], 640, 768, 80, 120)  # the object reaches into the last strip
+    B = 7
+    frames = [np.roll(base, 40 * b, axis=1) for b in range(B)]
+    frames[2] = np.full_like(base, 50)  # a constant frame inside a group of textured ones
+    buf = np.zeros((2 * B,) + base.shape, np.uint8)
+    buf[0::2] = np.stack(frames)
+    buf[1::2] = 255 - np.stack(frames)  # the frames in between must not be read
+    ctx = ctx_factory()
+    ctx.upload_templates(ts)
+    ctx.set_quantize_mode("stream", 16)
+    cap, rec = 1024, MATCH_DTYPE.itemsize
+    stream = torch.cuda.Stream(device=dev)
+    d_imgs = torch.from_numpy(buf).to(dev)
+    d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(B * 2, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.match_batch_device(d_imgs.data_ptr(), 2 * base.size, B, 640, 768, 768 * 3, 3, 80.0, d_out.data_ptr(), cap, d_cnt.data_ptr(),
+                           stream=stream.cuda_stream)
+    stream.synchronize()
+    cnt = d_cnt.cpu().numpy().reshape(-1, 2)
+    out = d_out.cpu().numpy().reshape(B, cap * rec)
+    total = 0
+    for f in range(B):
+        p = oracle.Pyramid.build(frames[f], [4, 8], 30.0)
+        want = p.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 80.0)
+        p.free()
+        assert cnt[f, 1] == 0 and cnt[f, 0] == len(want), f
+        assert key(out[f].view(MATCH_DTYPE)[: cnt[f, 0]]) == key(want), f
+        total += len(want)
+    assert total > 0
