@@ -481,17 +481,22 @@ __host__ __device__ inline int quantize_stream_items(const QSArgs& a)
 template <int CH>
 __device__ __forceinline__ void quantize_stream_item(const QSArgs& a, int item)
 {
+    // Order: row block slowest, then frame, then strip.  All work items are resident at once (one round) and the
+    // dispatcher deals workgroups to the 256 CUs round-robin, so a CU's three workgroups are 256 and 512 workgroups
+    // apart: with the frame slowest those were the SAME region of three different frames -- on a frame that is part
+    // constant canvas a CU got three textured or three constant workgroups (16 BASELINE frames: 77 us, the time of a
+    // fully textured batch); with the row block slowest they are a third of the image apart.
     const int n_full = a.pack_lanes ? a.n_strips - 1 : a.n_strips; // strips that get a wave per frame
-    const int per_frame = n_full * a.n_rblocks, n_plain = per_frame * a.frames;
+    const int per_rb = n_full * a.frames, n_plain = per_rb * a.n_rblocks;
     if (item < n_plain) {
-        const int frame = item / per_frame, r = item - frame * per_frame;
-        quantize_stream_wave<CH>(a, r % n_full, r / n_full, frame, 0);
+        const int rb = item / per_rb, r = item - rb * per_rb;
+        quantize_stream_wave<CH>(a, r % n_full, rb, r / n_full, 0);
     } else {
         const int j = item - n_plain;
         if (!a.pack_lanes || j >= a.n_rblocks * a.pack_groups) return;
-        const int grp = j / a.n_rblocks, per = 64 / a.pack_lanes, f0 = grp * per;
+        const int rb = j / a.pack_groups, grp = j - rb * a.pack_groups, per = 64 / a.pack_lanes, f0 = grp * per;
         const int nseg = a.frames - f0 < per ? a.frames - f0 : per;
-        quantize_stream_wave<CH>(a, a.n_strips - 1, j - grp * a.n_rblocks, f0, nseg);
+        quantize_stream_wave<CH>(a, a.n_strips - 1, rb, f0, nseg);
     }
 }
 
