@@ -11,7 +11,8 @@ Default workload (BASELINE.json configs[1], "case1 on 1x MI355X"): the reference
 1024 x 1024 BGR canvas, 360 case1 rotation templates (131 / 71 features) per GPU, pyramid {4, 8}, threshold 90.
 --batch frames per step (default 16: sbm_match_batch_device launches every kernel once for the batch; frame b is the
 workload frame shifted 8*b columns) and --inflight independent slots (contexts + streams, default 3) used
-round-robin.  The same line also carries the fully textured frame and the SURVEY 8d Stage-A frame (shapes + noise)
+round-robin; before the timed region a short probe picks the launch path (stream launches / hipGraph replay / one
+slot: config.launch).  The same line also carries the fully textured frame and the SURVEY 8d Stage-A frame (shapes + noise)
 as secondary, separately timed passes (config.textured_us_per_frame, config.stage_a_us_per_frame).
 
 Other BASELINE configurations (not the driver's line; --config):
