@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Randomised end-to-end check of the batch entry point against the CPU oracle (GPU box; test infrastructure).
+Random frame geometry (multiples of 16), channel count, batch size, template subset, threshold, mask, gradient-kernel
+mode and coarse-pass kernel; every frame's match multiset must equal the oracle's.
+usage: python tools/fuzz_match.py [n_cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from shape_based_matching_amd import capi, synth  # noqa: E402
+from shape_based_matching_amd.templates import MATCH_DTYPE, TemplateSet  # noqa: E402
+
+
+def multiset(recs):
+    return sorted(np.ascontiguousarray(recs, MATCH_DTYPE).tolist())
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rs = np.random.RandomState(seed)
+    O.build()
+    O.lib()
+    torch.cuda.init()
+    dev = torch.device("cuda", 0)
+    all_ts = TemplateSet.load_npz(os.path.join(ROOT, "tests", "golden", "case1_templates.npz"))
+    img = np.load(os.path.join(ROOT, "tests", "golden", "case1_test_bgr.npz"))["bgr"]
+    t0 = time.time()
+    n_matches = 0
+    for case in range(n_cases):
+        rows = 16 * int(rs.randint(30, 70))
+        cols = 64 * int(rs.randint(7, 18))  # the batch entry point wants (cols / T) % 4 == 0 at every level
+        ch = int(rs.choice([1, 3]))
+        B = int(rs.randint(1, 10))
+        n_t = int(rs.choice([1, 3, 7, 30, 90, 200]))
+        idx = sorted(rs.choice(all_ts.n_templates, n_t, replace=False).tolist())
+        ts = all_ts.subset(idx)
+        thr = float(rs.choice([55.0, 70.0, 80.0, 88.0, 93.0, 98.0]))
+        kind = rs.choice(["embed", "tile", "scene"])
+        frames = []
+        for b in range(B):
+            if kind == "scene":
+                fr = synth.scene_bgr(int(rs.randint(1 << 20)), rows, cols)
+            elif kind == "tile":
+                reps = (-(-rows // img.shape[0]), -(-cols // img.shape[1]), 1)
+                fr = np.roll(np.tile(img, reps)[:rows, :cols], int(rs.randint(0, 64)), axis=1)
+            else:
+                h, w = min(rows, img.shape[0]), min(cols, img.shape[1])
+                fr = synth.embed(img[:h, :w], rows, cols, int(rs.randint(0, rows - h + 1)), int(rs.randint(0, cols - w + 1)))
+            frames.append(np.ascontiguousarray(fr if ch == 3 else fr[:, :, 1]))
+        mask = None
+        if rs.randint(0, 4) == 0:
+            mask = np.zeros((rows, cols), np.uint8)
+            mask[rows // 8: rows - rows // 6, cols // 7: cols - cols // 9] = 255
+        os.environ["SBM_COARSE"] = str(rs.choice(["", "block", "wave"]))
+        qmode = str(rs.choice(["auto", "tile", "stream"]))
+        hs = int(rs.choice([0, 6, 8, 16, 28]))
+        ctx = capi.Context(T=(4, 8), weak_threshold=30.0, device_id=0)
+        ctx.upload_templates(ts)
+        ctx.set_quantize_mode(qmode, hs)
+        cap, rec = 8192, MATCH_DTYPE.itemsize
+        stream = torch.cuda.Stream(device=dev)
+        d_img = torch.from_numpy(np.stack(frames)).to(dev)
+        d_mask = torch.from_numpy(mask).to(dev) if mask is not None else None
+        d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)
+        d_cnt = torch.zeros(B * 2, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.match_batch_device(d_img.data_ptr(), frames[0].size, B, rows, cols, cols * ch, ch, thr, d_out.data_ptr(), cap, d_cnt.data_ptr(),
+                               d_mask=d_mask.data_ptr() if d_mask is not None else 0, stream=stream.cuda_stream)
+        stream.synchronize()
+        cnt = d_cnt.cpu().numpy().reshape(B, 2)
+        out = d_out.cpu().numpy().reshape(B, cap * rec)
+        desc = (case, rows, cols, ch, B, n_t, thr, kind, mask is not None, os.environ["SBM_COARSE"], qmode, hs)
+        for f in range(B):
+            pyr = O.Pyramid.build(frames[f], [4, 8], 30.0, mask=mask)
+            want = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr, n_threads=min(16, os.cpu_count() or 1))
+            pyr.free()
+            if len(want) > cap:
+                continue
+            assert cnt[f, 1] == 0 and cnt[f, 0] == len(want), (desc, f, cnt[f].tolist(), len(want))
+            assert multiset(out[f].view(MATCH_DTYPE)[: cnt[f, 0]]) == multiset(want), (desc, f)
+            n_matches += len(want)
+        ctx.close()
+        print("ok", desc, flush=True)
+    print(f"{n_cases} cases, {n_matches} matches compared, {time.time() - t0:.0f} s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
