@@ -21,9 +21,7 @@ def multiset(recs):
     return sorted(np.ascontiguousarray(recs, MATCH_DTYPE).tolist())
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def run(n_cases, seed, verbose=True):
     rs = np.random.RandomState(seed)
     O.build()
     O.lib()
@@ -87,9 +85,12 @@ def main():
             assert multiset(out[f].view(MATCH_DTYPE)[: cnt[f, 0]]) == multiset(want), (desc, f)
             n_matches += len(want)
         ctx.close()
-        print("ok", desc, flush=True)
-    print(f"{n_cases} cases, {n_matches} matches compared, {time.time() - t0:.0f} s", flush=True)
+        if verbose:
+            print("ok", desc, flush=True)
+    if verbose:
+        print(f"{n_cases} cases, {n_matches} matches compared, {time.time() - t0:.0f} s", flush=True)
+    return n_matches
 
 
 if __name__ == "__main__":
-    main()
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
