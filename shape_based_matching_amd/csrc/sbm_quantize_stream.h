@@ -214,11 +214,16 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
             }
             flat_cnt = row_flat ? (flat_cnt > 0 && key == flat_key ? flat_cnt + 1 : 1) : 0;
             flat_key = key;
-            const bool fast = flat_cnt >= 11; // source rows y-10 .. y are one constant colour
+            const bool long_run = flat_cnt >= 11; // source rows y-10 .. y are one constant colour
+            // ... or every row this work item has loaded so far is: nothing it will store can depend on anything else
+            // (its first stored row, i = 10, sees exactly the rows 0 .. 10), so a work item that starts inside a constant
+            // region skips the arithmetic of its warm-up rows too
+            const bool fast = long_run || flat_cnt == i + 1;
 
-            // ---- border replicate, de-interleave + widen into window slot k.  Skipped inside a constant run: the slot
-            //      holds row y-7, which is the same constant row ----
-            if (!fast) {
+            // ---- border replicate, de-interleave + widen into window slot k.  Skipped inside a long constant run: the
+            //      slot holds row y-7, which is the same constant row (a run that began with the work item still has
+            //      to fill the window) ----
+            if (!long_run) {
                 if (border_strip) {
                     if (CH == 3) {
                         const V n0 = perm(d[2 % ND], d[0], selA), n2 = perm(d[2 % ND], d[0], selC);

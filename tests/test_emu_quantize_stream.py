@@ -177,3 +177,25 @@ def test_packed_last_strip_of_several_frames(emu, oracle, case1):
     assert lanes == 0
     for f in range(3):
         assert np.array_equal(out[f], oracle.quantized_orientations(wide[f], 30.0)[1])
+
+
+def test_work_items_that_start_in_a_constant_region(emu, oracle):
+    """a work item whose rows so far are all one colour skips the arithmetic from its first row on (not only after 11
+    rows): texture arriving 1 .. 14 rows after an item's first loaded row, a colour change inside the constant start,
+    constant columns only (not a constant row), and the image's top border inside the constant start"""
+    rs = np.random.RandomState(21)
+    for ch in (1, 3):
+        shape = (96, 272) + ((3,) if ch == 3 else ())
+        for n in range(1, 15):
+            z = rs.randint(0, 256, shape).astype(np.uint8)
+            z[16:16 + n] = 90          # a constant band of n rows starting where the 8-row items of rb = 2, 3 load
+            z[40:40 + n] = 200 - n     # and another colour further down
+            z[60:64] = 33
+            z[64:70] = 34              # colour change inside a constant start
+            z[70:, :100] = 5           # constant columns, textured rest: never a constant row
+            check(emu, oracle, z, hs=8)
+            check(emu, oracle, z, hs=16)
+        top = rs.randint(0, 256, shape).astype(np.uint8)
+        top[:9] = 120                  # the image starts constant: the clamped rows above row 0 are the same colour
+        check(emu, oracle, top, hs=8)
+        check(emu, oracle, top, hs=32)
