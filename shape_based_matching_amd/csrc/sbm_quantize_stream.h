@@ -29,8 +29,13 @@
 // BORDER_REPLICATE of cv::Sobel never reaches the output: a pixel whose 3x3 window leaves the image is on the
 // 1-pixel ring that hysteresisGradient zeroes (:229-236), so only the Gaussian's replicate border is materialised.
 //
-// Constant-row shortcut: while the last 11 source rows of the strip are one constant colour, the output row is 0,
-// the pyrDown row is that colour and the carried state is known in closed form; such rows skip the arithmetic.
+// Constant-row shortcut: while the last 11 source rows of the strip are one constant colour -- or every row the work
+// item has loaded so far is -- the output row is 0, the pyrDown row is that colour and the carried state is known in
+// closed form; such rows skip the arithmetic.
+//
+// Batches: the narrow last strip of a row (cols - 240 k columns) of several frames shares one wave (QSArgs::pack_lanes),
+// and the work items are ordered row block first, so that the three workgroups a CU holds come from three regions of
+// the image (quantize_stream_item).
 //
 // Requires cols % 4 == 0 and cols >= 4 (every pyramid level of a match() frame with T in {4, 8, ...} satisfies
 // it); other geometries and the float outputs (magnitude / angle of the stage API and of training) stay with
