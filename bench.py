@@ -7,13 +7,16 @@ similarity over this rank's template shard -> 16x16 refinement -> match records 
 all-gathered over RCCL when N > 1 and stored in pinned host memory.  Metric: templates * Mpixels / s
 (BASELINE.json), whole job: templates x Mpixels x frames per step x steps / time.
 
-Default workload (BASELINE.json configs[1], "case1 on 1x MI355X"): the reference's case1 test image centred on a
-1024 x 1024 BGR canvas, 360 case1 rotation templates (131 / 71 features) per GPU, pyramid {4, 8}, threshold 90.
+Default workload (BASELINE.json configs[1], "case1 on 1x MI355X"): 1024 x 1024 BGR frames -- SURVEY 8d's Stage-A scene
+(random shapes + noise on every pixel) with the reference's case1 test image pasted at the centre, so that the figure
+does not depend on constant regions of the canvas --, 360 case1 rotation templates (131 / 71 features) per GPU, pyramid
+{4, 8}, threshold 90.
 --batch frames per step (default 16: sbm_match_batch_device launches every kernel once for the batch; frame b is the
 workload frame shifted 8*b columns) and --inflight independent slots (contexts + streams, default 3) used
 round-robin; before the timed region a short probe picks the launch path (stream launches / hipGraph replay / one
-slot: config.launch).  The same line also carries the fully textured frame and the SURVEY 8d Stage-A frame (shapes + noise)
-as secondary, separately timed passes (config.textured_us_per_frame, config.stage_a_us_per_frame).
+slot: config.launch).  The same line also carries, as secondary, separately timed passes: the reference's own demo frame
+(the test image on a black canvas, config.value_case1_canvas: 65 % constant pixels, the gradient kernel's best case), the
+image tiled over the canvas (config.value_textured) and the scene without the object (config.value_stage_a).
 
 Other BASELINE configurations (not the driver's line; --config):
   c3  2048^2, 3600 templates x 63/31 features          template loop on Stage-B maps, template-sharded
@@ -59,7 +62,9 @@ def case1_templates(n):
 
 
 def case1_frame(kind, rows, cols):
-    """case1: the reference's test image centred on a black canvas (test.cpp:344-353 pads it the same way);
+    """scene: SURVEY 8d's Stage-A scene (random filled shapes + noise in [-2, 2] on every pixel) with the reference's
+    case1 test image pasted at the centre -- no constant region, and the trained object is there to be found;
+    case1: the reference's test image centred on a black canvas (test.cpp:344-353 pads it the same way);
     tiled: the image repeated over the whole canvas (no constant region anywhere);
     stagea: SURVEY 8d's Stage-A input — black background, random filled rectangles / ellipses, noise in [-2, 2]."""
     from shape_based_matching_amd import synth
@@ -70,6 +75,8 @@ def case1_frame(kind, rows, cols):
         return np.ascontiguousarray(np.tile(img, reps)[:rows, :cols])
     if kind == "stagea":
         return synth.scene_bgr(1234, rows, cols)
+    if kind == "scene":
+        return synth.scene_with_object(1234, rows, cols, img)
     return synth.embed(img, rows, cols, (rows - img.shape[0]) // 2, (cols - img.shape[1]) // 2)
 
 
@@ -78,7 +85,7 @@ class Workload:
     stage = "templates": the template loop on Stage-B orientation maps that are uploaded once."""
 
 
-def make_workload(args, world):
+def make_workload(args, world, rank=0):
     from shape_based_matching_amd import synth
 
     w = Workload()
@@ -96,7 +103,9 @@ def make_workload(args, world):
         w.desc = (f"case1 on MI355X: 1024x1024x3 frames x {per} templates {'per GPU' if args.scaling == 'weak' else 'in total'} "
                   f"(131/71 features), pyramid T={{4,8}}, threshold 90, {w.batch} frame(s) per step, every frame's match list "
                   "gathered to the host every step")
-        w.data = {"case1": "reference case1 test image (test/case1/test.png) centred on a black 1024x1024 BGR canvas; ",
+        w.data = {"scene": "SURVEY 8d Stage-A scene (random shapes + noise on every pixel) 1024x1024 BGR with the reference case1 "
+                           "test image (test/case1/test.png) pasted at the centre; ",
+                  "case1": "reference case1 test image (test/case1/test.png) centred on a black 1024x1024 BGR canvas; ",
                   "tiled": "reference case1 test image (test/case1/test.png) tiled over the whole 1024x1024 BGR canvas; ",
                   "stagea": "SURVEY 8d Stage-A scene (random shapes + noise) 1024x1024 BGR; "}[args.frame] + \
             "case1 rotation templates 0..359 (test/case1/test_templ.yaml)"
@@ -106,11 +115,17 @@ def make_workload(args, world):
         nf, box, total = ([63, 31], 260, 3600) if args.config == "c3" else ([8191, 4095], 1024, 36000)
         total = args.templates or total
         n = total * world if args.scaling == "weak" else total
-        w.maps, w.ts = synth.stage_b(1234, w.rows, w.cols, T_LEVELS, n, nf, templ_size=box, plant_every=40)
+        # every template has the same number of features and positions: equal contiguous ranges are work-balanced, and a
+        # rank generates only its own shard (stage_b_fixed: per-template random streams, a fixed number of plants)
+        w.n_total = n
+        w.range = (rank * n // world, (rank + 1) * n // world - rank * n // world)
+        plants = 32 if args.config == "c3" else 16
+        w.maps, w.ts = synth.stage_b_fixed(1234, w.rows, w.cols, T_LEVELS, n, nf, templ_size=box, n_plants=plants,
+                                           first=w.range[0], count=w.range[1])
         w.frames = None
-        w.desc = (f"BASELINE config {args.config[1]}: {w.rows}x{w.cols} Stage-B orientation maps (2 % one-hot density, every 40th "
-                  f"template planted), {n} templates x {nf[0]}/{nf[1]} features, template loop (coarse pass + refinement) per step")
-        w.data = "synthetic Stage-B inputs (SURVEY 8d), seed 1234"
+        w.desc = (f"BASELINE config {args.config[1]}: {w.rows}x{w.cols} Stage-B orientation maps (2 % one-hot density + {plants} "
+                  f"planted templates), {n} templates x {nf[0]}/{nf[1]} features, template loop (coarse pass + refinement) per step")
+        w.data = "synthetic Stage-B inputs (SURVEY 8d generator with a fixed number of plants: synth.stage_b_fixed), seed 1234"
     else:  # c5
         w.rows, w.cols, w.ch, w.stage = 1072, 1920, 3, "match"
         w.shard = "frames"
@@ -165,8 +180,8 @@ def cpu_baseline(ts, frame, budget_s: float = 12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=None, help="default: 1000 (case1), 200 (c3), 50 (c5), 10 (c4)")
+    ap.add_argument("--warmup", type=int, default=None, help="default: a tenth of the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--force-collective", action="store_true",
@@ -178,14 +193,20 @@ def main():
     ap.add_argument("--batch", type=int, default=16,
                     help="frames per step: a step is one sbm_match_batch_device call over this many frames (distinct "
                          "horizontal shifts of the workload frame); 1 = one sbm_match_device call per step")
-    ap.add_argument("--frame", choices=("case1", "tiled", "stagea"), default="case1",
-                    help="case1: the reference's test image centred on a black canvas (BASELINE configs[1]); tiled: the same "
-                         "image repeated over the whole canvas; stagea: SURVEY 8d's shapes + noise scene")
+    ap.add_argument("--frame", choices=("scene", "case1", "tiled", "stagea"), default="scene",
+                    help="scene (default): SURVEY 8d's shapes + noise scene with the case1 test image pasted in (no constant "
+                         "region: a content-independent figure); case1: the reference's test image centred on a black canvas "
+                         "(65 %% constant: the gradient kernel's constant-row shortcut applies); tiled: the image repeated over "
+                         "the whole canvas; stagea: the scene without the object")
     ap.add_argument("--config", choices=("case1", "c3", "c4", "c5"), default="case1")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--templates", type=int, default=0, help="override the configuration's template count")
     ap.add_argument("--no-extra-frames", action="store_true", help="skip the secondary (textured / Stage-A) passes")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"case1": 1000, "c3": 200, "c4": 10, "c5": 50}[args.config]
+    if args.warmup is None:
+        args.warmup = max(2, args.steps // 10)
     if args.inflight <= 0:
         args.inflight = 3 if args.config == "case1" else 2
     # More than 3 slots is not a win on a stock runtime: HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware
@@ -214,10 +235,13 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    wl = make_workload(args, world)
+    wl = make_workload(args, world, rank)
     ts = wl.ts
     ROWS, COLS, CH = wl.rows, wl.cols, wl.ch
-    if wl.shard == "templates":
+    if wl.maps is not None:  # Stage-B template loops: this rank generated exactly its shard
+        first, count = 0, ts.n_templates
+        my_frames = None
+    elif wl.shard == "templates":
         first, count = sharding.partition(sharding.coarse_work(ts, ROWS, COLS, T_LEVELS), world)[rank]
         my_frames = np.arange(wl.batch) if wl.frames is not None else None
     else:  # frames dealt rank::world, templates replicated
@@ -386,7 +410,7 @@ def main():
             c = sl.host_counts()
             if ref_counts is None:
                 ref_counts = c
-            if not np.array_equal(c, ref_counts) or (wl.stage == "match" and args.config == "case1" and c[:, :, 0].min() <= 0):
+            if not np.array_equal(c, ref_counts):
                 raise SystemExit(f"unstable match counts: {c.tolist()} vs {ref_counts.tolist()}")
     counts = slots[0].host_counts()
     if (counts[:, :, 1] != 0).any() or (counts[:, :, 0] > cap).any():
@@ -441,9 +465,9 @@ def main():
 
     # secondary frames of the default workload: same engine, same templates, other pixels (separately timed)
     extra = {}
-    if args.config == "case1" and args.frame == "case1" and not args.no_extra_frames and wl.stage == "match":
+    if args.config == "case1" and args.frame == "scene" and not args.no_extra_frames and wl.stage == "match":
         keep = d_img.clone()
-        for kind, key in (("tiled", "textured"), ("stagea", "stage_a")):
+        for kind, key in (("case1", "case1_canvas"), ("tiled", "textured"), ("stagea", "stage_a")):
             fr = case1_frame(kind, ROWS, COLS)
             d_img.copy_(torch.from_numpy(np.stack([np.roll(fr, 8 * b, axis=1) for b in range(B)])).to(dev))
             n = max(20, min(args.steps, 300))
@@ -485,15 +509,23 @@ def main():
         dom_bytes = float(sum(alg[dom])) / kern[dom]["launches"]
         dom_s = kern[dom]["avg_launch_us"] * 1e-6
         achieved = dom_bytes / dom_s / 1e9
+        # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE, WRITE_SIZE in
+        # separate runs, gfx950 correction applied: profiles/pmc_traffic.json, tools/make_pmc_json.py).  For the kernels
+        # that no longer touch all their algorithmic bytes (k_build_lm writes one spread plane instead of eight at the
+        # refinement levels; the coarse pass prunes) the fraction of the HBM roofline is the counter-based one.
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and args.config == "case1":
+        if os.path.exists(pmc) and args.config == "case1" and B == 16:
             try:
-                traffic = json.load(open(pmc)).get(dom)
+                pj = json.load(open(pmc))
+                for name in kern:
+                    if name in pj:
+                        kern[name]["hbm_traffic_bytes_per_launch"] = float(pj[name])
+                        kern[name]["hbm_frac"] = float(pj[name]) / (kern[name]["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                traffic = pj.get(dom)
             except Exception:
                 traffic = None
-        step_bytes = float(sum(sum(v) for k, v in alg.items() if k in kern))
-        total_templates = ts.n_templates
+        total_templates = wl.n_total if wl.maps is not None else ts.n_templates
         frames_per_step_total = (wl.total_frames if wl.shard == "frames" else B)
         value = total_templates * (ROWS * COLS / 1e6) * frames_per_step_total * args.steps / elapsed
         cfg = {
@@ -518,12 +550,16 @@ def main():
             "coarse_candidates_rank0": n_cand,
         }
         if extra:
-            # the same step on a frame without constant regions and on the SURVEY 8d Stage-A scene: `value` is the
-            # BASELINE configuration (65 % of its canvas is constant), these are the content-independent figures
+            # the same step on other pixels: the BASELINE configs[1] frame as the reference's demo builds it (the test image
+            # on a black canvas: 65 % constant, where the gradient kernel's constant-row shortcut applies -- a best case,
+            # not the headline), the image tiled over the canvas, and the scene without the object
+            per_us = lambda key: total_templates * (ROWS * COLS / 1e6) / (extra[key]["us_per_frame"] * 1e-6)  # noqa: E731
+            cfg["value_case1_canvas"] = per_us("case1_canvas")
+            cfg["value_textured"] = per_us("textured")
+            cfg["value_stage_a"] = per_us("stage_a")
+            cfg["case1_canvas_us_per_frame"] = extra["case1_canvas"]["us_per_frame"]
             cfg["textured_us_per_frame"] = extra["textured"]["us_per_frame"]
             cfg["stage_a_us_per_frame"] = extra["stage_a"]["us_per_frame"]
-            cfg["value_textured"] = total_templates * (ROWS * COLS / 1e6) / (extra["textured"]["us_per_frame"] * 1e-6)
-            cfg["value_stage_a"] = total_templates * (ROWS * COLS / 1e6) / (extra["stage_a"]["us_per_frame"] * 1e-6)
             cfg["other_frames"] = extra
         out = {
             "metric": "templates*Mpixels/sec (whole Detector::match, frame resident in HBM)" if wl.stage == "match"
@@ -554,9 +590,13 @@ def main():
                 "note": "per launch = the frames of one step; figures are the mean over this kernel's launches of a step "
                         "(k_quantize: one launch per pyramid level).  `bound` names the roofline the fraction is taken against "
                         "(HBM, as BASELINE's north_star asks); `limiter` is what the counters say actually bounds the kernel",
-                "whole_step": {"algorithmic_bytes": step_bytes,
-                               "achieved": step_bytes / (elapsed / args.steps) / 1e9,
-                               "frac": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+                # the whole step against HBM, from the counters (sum over the step's launches / time of the pipelined step)
+                "whole_step": ({"hbm_traffic_bytes": float(sum(v["hbm_traffic_bytes_per_launch"] * v["launches"] for v in kern.values()
+                                                               if "hbm_traffic_bytes_per_launch" in v)),
+                                "ms_per_step": elapsed / args.steps * 1e3,
+                                "hbm_frac": float(sum(v["hbm_traffic_bytes_per_launch"] * v["launches"] for v in kern.values()
+                                                      if "hbm_traffic_bytes_per_launch" in v)) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}
+                               if traffic is not None else None),
             },
             "kernels": kern,
         }

@@ -398,9 +398,10 @@ int quantize_stream_rows(const sbm_ctx* c, int rows, int cols, int ch, int frame
     const int64_t per_rb = pack ? (strips - 1) * frames + (frames + 64 / pack - 1) / (64 / pack) : strips * frames;
     int hs = 0;
     int64_t best = INT64_MAX;
-    for (int h = 6; h <= 128; h += 2) {
+    // a work item runs whole groups of 7 row iterations (sbm_quantize_stream.h): rows + 10 warm-up / drain, rounded up
+    for (int h = 4; h <= 130; h += 2) {
         const int64_t waves = per_rb * ((rows + h - 1) / h);
-        const int64_t cost = ((waves + slots - 1) / slots) * (std::min(h, rows) + 10);
+        const int64_t cost = ((waves + slots - 1) / slots) * ((std::min(h, rows) + 10 + 6) / 7 * 7);
         if (cost <= best) best = cost, hs = h;
     }
     // small launches: the 16 x 64 tiles of k_quantize finish sooner than a few long serial chains

@@ -113,7 +113,11 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
     using namespace wv;
     constexpr int ND = CH == 3 ? 3 : 1; // source dwords per lane and row
     const int rows = a.rows, cols = a.cols;
-    const int R0 = rb * a.hs;
+    // Every work item owns exactly min(hs, rows) output rows: the last row block is moved up to end at the image's last
+    // row (it then recomputes a few rows of the block above -- the same bytes, stored twice).  All items of a launch run
+    // the same number of row iterations, in whole groups of 7 (see the row loop).
+    int R0 = rb * a.hs;
+    if (R0 + a.hs > rows) R0 = rows > a.hs ? rows - a.hs : 0;
     const int R1 = R0 + a.hs < rows ? R0 + a.hs : rows;
     const int cb = strip * QS_USEFUL - QS_HALO_LANES * QS_LANE_PX; // column of lane 0, pixel 0
     const uint8_t* img = a.img + (int64_t)frame * a.img_fs;
@@ -191,11 +195,19 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
     uint32_t flat_key = 0;    // that colour
     bool in_run = false;      // the previous row took the constant-row shortcut (the carried state is already constant)
 
-    for (int i0 = 0; i0 < n_iter; i0 += 7) {
+    // The row loop runs whole groups of 7 iterations (the window's rotation period, unrolled so that every register
+    // index is static) and never leaves a group early: an iteration that is skipped hands every carried value on
+    // UNCHANGED, while one that runs hands its two-row carries on EXCHANGED (x2 <- x1, x1 <- new); with both kinds of
+    // edges into the same join the register allocator has to copy the whole state every row (36 v_mov per row and lane
+    // measured).  Iterations past n_iter (at most 6, none when hs + 10 is a multiple of 7, which is what the host picks)
+    // compute on clamped rows and store nothing.
+    const int n_groups = (n_iter + 6) / 7;
+    for (int grp = 0; grp < n_groups; ++grp) {
+        const int i0 = grp * 7;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const int i = i0 + k;
-            if (i >= n_iter) break;
+            const bool store_row = i >= 10 && i < n_iter; // this iteration's output row yv is one of the item's rows
             const int y = R0 - 5 + i; // source row entering the window (slot k)
             // unconditional (rows past the end re-read the clamped last row): a conditional write would keep all
             // seven ring entries live across the loop
@@ -307,12 +319,12 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
                 }
             }
 
-            if (fast) {
+            if (__builtin_expect(fast, 0)) {
                 // The output row is 0, and the state the next row needs is known in closed form: smoothed rows y-3, y-4
                 // are the colour c (dx = 0, sx = 4c), the vote words of rows y-4, y-5 are bin 0 (3 per horizontal sum),
                 // nothing is strong in row y-4.
-                if (i >= 10) buf_store_u32(out_buf, out_off, out_row, splat(0u));
-                if (!in_run) { // first row of the run: the following ones leave the state as it is
+                if (store_row) buf_store_u32(out_buf, out_off, out_row, splat(0u));
+                if (!in_run) { // first row of the run
                 in_run = true;
 #pragma unroll
                 for (int c = 0; c < CH; ++c)
@@ -326,6 +338,27 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
                 for (int j = 0; j < 4; ++j) {
                     st.hs1[j] = st.hs2[j] = cold_splat(3u);
                     st.sm1[j] = cold_splat(0u);
+                }
+                } else {
+                // Inside a run both rows of every two-row carry hold the same constants, so the row may hand them on
+                // EXCHANGED -- which is what a textured row does with its names (x2 <- x1, x1 <- new): the register
+                // allocator can then give "x2 after this row" the register of "x1 before it" on both paths, and the
+                // textured path carries its state without a single copy (36 v_mov per row before).
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const V td = st.dx2[c][h], tsx = st.sx2[c][h];
+                        st.dx2[c][h] = st.dx1[c][h];
+                        st.dx1[c][h] = td;
+                        st.sx2[c][h] = st.sx1[c][h];
+                        st.sx1[c][h] = tsx;
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const V th = st.hs2[j];
+                    st.hs2[j] = st.hs1[j];
+                    st.hs1[j] = th;
                 }
                 }
             } else {
@@ -384,7 +417,10 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
 #pragma unroll
                 for (int c = 0; c < CH; ++c)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) dxc[c][h] = sxc[c][h] = dont_care();
+                    for (int h = 0; h < 2; ++h) {
+                        dxc[c][h] = dont_care();
+                        sxc[c][h] = dont_care();
+                    }
             }
 
             // ---- Sobel vertical combine, magnitude, channel select, vote words of row ys ----
@@ -407,7 +443,7 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
                     v[3] = perm(gy[1], gx[1], 0x07060302u);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const V mg = sdot2(v[j], v[j], 0u);
+                        const V mg = sdot2_small(v[j], v[j]); // |gx|, |gy| <= 1020: no overflow
                         if (c == 0) {
                             bv[j] = v[j];
                             bm[j] = mg;
@@ -444,7 +480,7 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
             }
 
             // ---- 3x3 majority vote of row yv ----
-            if (i >= 10) {
+            if (store_row) {
                 V packed = splat(0u);
                 if (yv >= 1 && yv <= rows - 2) {
                     V val[4];

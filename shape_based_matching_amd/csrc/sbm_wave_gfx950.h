@@ -30,8 +30,15 @@ __device__ __forceinline__ V cold_splat(uint32_t s)
     asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(s));
     return r;
 }
-// a value nobody reads: no instruction, no register copy at control-flow joins
-__device__ __forceinline__ V dont_care() { return __builtin_nondeterministic_value((V)0); }
+// a value nobody reads: an empty asm "defines" it where it is written, so the register allocator simply gives it the
+// register of the value it joins -- no instruction, and nothing the optimiser could materialise as a constant in
+// front of the branch (__builtin_nondeterministic_value became 12 x v_mov 0 per row on the common path)
+__device__ __forceinline__ V dont_care()
+{
+    V r;
+    asm volatile("" : "=v"(r));
+    return r;
+}
 
 // lane i <- lane i-1 (v_mov_b32_dpp wave_shr:1 bound_ctrl:0); lane 0 reads 0
 __device__ __forceinline__ V from_left(V x) { return (V)__builtin_amdgcn_mov_dpp((int)x, 0x138, 0xf, 0xf, true); }
@@ -57,6 +64,14 @@ __device__ __forceinline__ V udot2(V a, V b, V c)
 __device__ __forceinline__ V sdot2(V a, V b, V c)
 {
     return (V)__builtin_amdgcn_sdot2(__builtin_bit_cast(wv_ss2, a), __builtin_bit_cast(wv_ss2, b), (int)c, false);
+}
+
+// a.lo*b.lo + a.hi*b.hi for operands whose sum cannot leave the int32 range (the caller guarantees it): the clamp bit
+// then changes nothing, but it selects the VOP3P encoding v_dot2_i32_i16 with an inline 0 addend -- the plain form is
+// matched to the VOP2 v_dot2c_i32_i16, whose accumulator is tied to the destination and costs a v_mov 0 per use
+__device__ __forceinline__ V sdot2_small(V a, V b)
+{
+    return (V)__builtin_amdgcn_sdot2(__builtin_bit_cast(wv_ss2, a), __builtin_bit_cast(wv_ss2, b), 0, true);
 }
 
 // packed 2 x 16-bit lanes, wrap-around (v_pk_add_u16, v_pk_sub_u16, v_pk_mul_lo_u16, v_pk_mad_u16, v_pk_max_i16,

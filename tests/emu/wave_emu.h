@@ -93,6 +93,16 @@ inline int32_t sdot2_1(uint32_t a, uint32_t b, int32_t c)
 }
 inline V sdot2(const V& a, const V& b, uint32_t c) { V r; WV_FOR r.l[i] = (uint32_t)sdot2_1(a.l[i], b.l[i], (int32_t)c); return r; }
 inline V sdot2(const V& a, uint32_t b, uint32_t c) { V r; WV_FOR r.l[i] = (uint32_t)sdot2_1(a.l[i], b, (int32_t)c); return r; }
+// v_dot2_i32_i16 ... 0 clamp: saturating; the int64 sum shows an operand pair that would make the clamp matter
+inline V sdot2_small(const V& a, const V& b)
+{
+    V r;
+    WV_FOR {
+        int64_t s = (int64_t)(int16_t)(a.l[i] & 0xffff) * (int16_t)(b.l[i] & 0xffff) + (int64_t)(int16_t)(a.l[i] >> 16) * (int16_t)(b.l[i] >> 16);
+        r.l[i] = (uint32_t)(int32_t)(s > INT32_MAX ? INT32_MAX : (s < INT32_MIN ? INT32_MIN : s));
+    }
+    return r;
+}
 
 #define WV_PK2(NAME, EXPR)                                                                         \
     inline uint32_t NAME##1(uint32_t a, uint32_t b)                                                \

@@ -199,3 +199,17 @@ def test_work_items_that_start_in_a_constant_region(emu, oracle):
         top[:9] = 120                  # the image starts constant: the clamped rows above row 0 are the same colour
         check(emu, oracle, top, hs=8)
         check(emu, oracle, top, hs=32)
+
+
+@pytest.mark.parametrize("ch", [1, 3])
+def test_whole_groups_of_seven_rows_and_overlapping_last_block(emu, oracle, ch):
+    """Round 3: a work item runs whole groups of 7 row iterations (no early exit from a group) and the last row block is
+    moved up to end at the image's last row.  Rows per item whose 10 warm-up / drain rows do (4, 18, 32, 46) and do not
+    (2, 8, 20, 30) fill the last group; heights that are not a multiple of the rows per item, an odd height, an image
+    shorter than one item, constant bands crossing the overlap of the last two blocks."""
+    rs = np.random.RandomState(31)
+    for rows in (50, 61, 96):
+        img = rs.randint(0, 256, (rows, 248) + ((3,) if ch == 3 else ())).astype(np.uint8)
+        img[rows - 20:rows - 6] = 77  # a constant band inside the rows the last two blocks both compute
+        for hs in (2, 4, 8, 18, 20, 30, 32, 46, 130):
+            check(emu, oracle, img, hs=hs)

@@ -43,6 +43,27 @@ def test_config4_full_geometry_max_features(oracle, ctx_factory):
     run_stage_b(oracle, ctx_factory, 4096, 4096, 24, [8191, 4095], 1024, plant_every=6)
 
 
+def test_config4_thousand_template_shard_of_the_full_set(oracle, ctx_factory):
+    """A 1024-template shard (templates 4000 .. 5023, which hold the plant at 4500) of BASELINE config 4's full 36 000
+    x 8191 / 4095-feature set on 4096^2 maps, generated the way bench.py --config c4 generates a rank's shard
+    (synth.stage_b_fixed: the number of planted templates does not grow with the template count, so the maps keep their
+    sparse density and the candidate list stays small at any shard size)."""
+    T = (4, 8)
+    maps, ts = synth.stage_b_fixed(1234, 4096, 4096, T, 36000, [8191, 4095], templ_size=1024, n_plants=16, first=4000, count=1024)
+    assert ts.template_id[0] == 4000 and ts.n_templates == 1024
+    ctx = ctx_factory(T=T, max_candidates=1 << 22)
+    ctx.upload_templates(ts)
+    for l in range(2):
+        ctx.set_quantized(l, maps[l])
+    got = ctx.match_templates(90.0)
+    pyr = oracle.Pyramid.from_quantized(maps, T)
+    want = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 90.0, n_threads=min(16, os.cpu_count() or 1))
+    assert len(want) > 0 and {int(r[5]) for r in np.ascontiguousarray(want, MATCH_DTYPE).tolist()} == {4500}
+    assert multiset(got) == multiset(want)
+    assert ctx.coarse_bytes() == pyr.coarse_bytes(ts.levels, ts.features)
+    pyr.free()
+
+
 def test_config5_one_frame_all_templates(oracle, ctx_factory):
     """1920 x 1072 (the 1080p frame cropped to multiples of 16, test.cpp:349-353), 1000 templates x 128 / 64"""
     run_stage_b(oracle, ctx_factory, 1072, 1920, 1000, [128, 64], 260, plant_every=40)
