@@ -91,6 +91,7 @@ def make_workload(args, world, rank=0):
     w = Workload()
     w.name, w.scaling = args.config, args.scaling
     w.shard = "templates"
+    w.partition = "templates"
     w.maps = None
     if args.config == "case1":
         w.rows = w.cols = 1024
@@ -98,8 +99,15 @@ def make_workload(args, world, rank=0):
         per = args.templates or 360
         w.ts = case1_templates(per * world if args.scaling == "weak" else per)
         w.batch = max(1, args.batch)
+        part = args.partition
+        if part == "auto":
+            part = "frames" if (args.scaling == "strong" and world > 1 and w.batch % world == 0) else "templates"
+        w.partition = part
+        if part == "frames":
+            w.shard = "frames"
+            w.total_frames = w.batch * world if args.scaling == "weak" else w.batch
         frame = case1_frame(args.frame, w.rows, w.cols)
-        w.frames = np.stack([np.roll(frame, 8 * b, axis=1) for b in range(w.batch)])
+        w.frames = np.stack([np.roll(frame, 8 * b, axis=1) for b in range(w.total_frames if part == "frames" else w.batch)])
         w.desc = (f"case1 on MI355X: 1024x1024x3 frames x {per} templates {'per GPU' if args.scaling == 'weak' else 'in total'} "
                   f"(131/71 features), pyramid T={{4,8}}, threshold 90, {w.batch} frame(s) per step, every frame's match list "
                   "gathered to the host every step")
@@ -201,6 +209,17 @@ def main():
     ap.add_argument("--config", choices=("case1", "c3", "c4", "c5"), default="case1")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--templates", type=int, default=0, help="override the configuration's template count")
+    ap.add_argument("--partition", choices=("auto", "templates", "frames", "bands"), default="auto",
+                    help="how a step is divided over the ranks (case1): templates = contiguous template ranges, every rank "
+                         "builds the whole pyramid (the reference's OpenMP loop, line2Dup.cpp:1166-1170); frames = the frames of "
+                         "the batch dealt over the ranks, all templates each (no exchange but the match lists); bands = "
+                         "build-sharded: row band r of every level's orientation map on rank r + all-gather of the bands + "
+                         "template ranges (sbm_match_batch_device_banded).  auto: templates for weak scaling, frames for "
+                         "strong scaling of a batch that divides over the ranks")
+    ap.add_argument("--bands", type=int, default=0,
+                    help="one GPU only: run every step through the band-sharded entry point with this many row bands (all "
+                         "computed here, one launch per band and level) -- the rehearsal of --partition bands")
+    ap.add_argument("--no-strong-estimate", action="store_true", help="skip the measured strong-scaling estimate (N = 1)")
     ap.add_argument("--no-extra-frames", action="store_true", help="skip the secondary (textured / Stage-A) passes")
     args = ap.parse_args()
     if args.steps is None:
@@ -258,6 +277,10 @@ def main():
     HDR = (8 * B + 15) // 16 * 16
     BUF = HDR + B * cap * REC
     native_gather = collective and wl.stage == "match"  # the library issues ncclAllGather on the kernels' stream
+    n_bands = world if (world > 1 and wl.partition == "bands") else (args.bands if world == 1 else 0)
+    banded = wl.stage == "match" and n_bands > 0 and args.config == "case1"
+    if banded and B < 1:
+        raise SystemExit("--partition bands needs a batch")
 
     class Slot:
         """one step in flight: its own engine context (device buffers), stream and result buffers"""
@@ -278,7 +301,7 @@ def main():
             self.d_buf = torch.zeros(BUF, dtype=torch.uint8, device=dev)          # this rank: header + records
             self.g_buf = torch.zeros(world * BUF, dtype=torch.uint8, device=dev)  # all ranks, gathered
             self.h_buf = torch.zeros(world * BUF, dtype=torch.uint8).pin_memory()
-            if not collective:
+            if not collective and not banded:
                 # single GPU: the last kernel stores the match list straight into pinned host memory
                 self.ctx.set_result_mirror(self.h_buf.data_ptr() + HDR, self.h_buf.data_ptr())
             elif native_gather:
@@ -297,6 +320,13 @@ def main():
                     with torch.cuda.stream(self.stream):
                         dist.all_gather_into_tensor(self.g_buf, self.d_buf)
                         self.h_buf.copy_(self.g_buf, non_blocking=True)
+            elif banded:
+                # build-sharded step: row bands of the gradient stage + all-gather of the orientation maps + template
+                # ranges + gather of the lists (one GPU: all bands here, one launch per band and level)
+                self.ctx.match_batch_device_banded(d_img.data_ptr(), FRAME_BYTES, B, ROWS, COLS, COLS * CH, CH, THRESHOLD,
+                                                   self.d_buf.data_ptr(), cap, self.g_buf.data_ptr() if collective else 0,
+                                                   gathered_mirror=self.h_buf.data_ptr(), n_bands=0 if world > 1 else n_bands,
+                                                   stream=s)
             elif native_gather and B > 1:
                 self.ctx.match_batch_device_sharded(d_img.data_ptr(), FRAME_BYTES, B, ROWS, COLS, COLS * CH, CH, THRESHOLD,
                                                     self.d_buf.data_ptr(), cap, self.g_buf.data_ptr(),
@@ -373,7 +403,7 @@ def main():
     graph_env = os.environ.get("SBM_GRAPH", "0") not in ("", "0")
     if graph_env:
         launch["path"] = "hipGraph replay (SBM_GRAPH)"
-    elif wl.stage == "match" and B > 1 and not os.environ.get("SBM_BENCH_NO_ADAPT"):
+    elif wl.stage == "match" and B > 1 and not banded and not os.environ.get("SBM_BENCH_NO_ADAPT"):
         t_stream = probe()
         for sl in slots:
             sl.ctx.set_graph_mode(True)
@@ -430,7 +460,8 @@ def main():
             batched = capi.canonicalize(recs[0, b, : counts[0, b, 0]].copy())
             if n1 != counts[0, b, 0] or single.tobytes() != batched.tobytes():
                 raise SystemExit(f"frame {b} of the batch differs from its single-frame match list")
-        ctx.set_result_mirror(slots[0].h_buf.data_ptr() + HDR, slots[0].h_buf.data_ptr())
+        if not banded:
+            ctx.set_result_mirror(slots[0].h_buf.data_ptr() + HDR, slots[0].h_buf.data_ptr())
     # frame 0 of the step: every rank's list, gathered (frame-sharded: rank 0's first frame)
     src_ranks = range(world) if wl.shard == "templates" else range(1)
     matches = np.concatenate([recs[r, 0, : counts[r, 0, 0]] for r in src_ranks])
@@ -462,6 +493,75 @@ def main():
     kern = kernel_pass(prof_steps)
     n_cand, refine_bytes = ctx.stats()
     coarse_bytes = ctx.coarse_bytes()
+
+    # Strong scaling of THIS step (the same B frames x the same templates divided over N GPUs), estimated from what one
+    # rank of an N-GPU job would run, measured here on one GPU.  Three partitions:
+    #   templates  contiguous template ranges, the whole pyramid built on every rank (the reference's OpenMP loop)
+    #   bands      build-sharded: the rank's row band of every orientation map (all N band launches run here, the rank's
+    #              time is the slowest band's), whole linear memories, 1 / N of the templates; + a MODEL of the all-gather
+    #              of the maps (it cannot be measured on one GPU)
+    #   frames     B / N frames, all templates: nothing exchanged but the match lists
+    # Every figure is the one-batch-at-a-time kernel time of a rank's share (per-kernel timestamps), so it compares with
+    # config.ms_per_step_one_batch_at_a_time; "speedup" = that / the rank's time (+ the modelled exchange for bands).
+    strong = None
+    if (world == 1 and args.config == "case1" and wl.stage == "match" and B >= 8 and not banded and not args.no_strong_estimate
+            and not args.no_extra_frames):
+        XGMI_LINK_GBS = 50.0   # assumed payload rate of ONE xGMI link in one direction (peak 76.5 of the 153 GB/s pair)
+        XGMI_LATENCY_US = 12.0  # assumed fixed cost of one grouped all-gather launch over 8 ranks
+        sl = slots[0]
+
+        def kernel_us(run, n=20):
+            sl.ctx.set_profiling(True, accumulate=True)
+            for _ in range(n):
+                run()
+            fence()
+            per = {}
+            for name, ms in sl.ctx.timings():
+                per.setdefault(name, []).append(ms * 1e3)
+            sl.ctx.set_profiling(False)
+            return {k: np.asarray(v).reshape(n, -1).mean(axis=0) for k, v in per.items()}
+
+        base = kernel_us(sl.run)
+        t1 = float(sum(v.sum() for v in base.values()))
+        strong = {"one_gpu_kernels_us_per_step": t1, "assumed_xgmi_link_GBps": XGMI_LINK_GBS, "assumed_all_gather_latency_us": XGMI_LATENCY_US,
+                  "note": "kernel time of one rank's share of the same step, measured on this GPU (one batch at a time); the "
+                          "bands row adds a modelled all-gather of the orientation maps (1 byte per pixel and level, every "
+                          "peer's band over its own xGMI link)"}
+        s0 = sl.stream.cuda_stream
+        out_p, cnt_p = sl.d_buf.data_ptr() + HDR, sl.d_buf.data_ptr()
+        sl.ctx.set_result_mirror(0, 0)
+        for n in (2, 4, 8):
+            if B % n:
+                continue
+            e = {}
+            # frames: B / n frames, all templates
+            kf = kernel_us(lambda: sl.ctx.match_batch_device(d_img.data_ptr(), FRAME_BYTES, B // n, ROWS, COLS, COLS * CH, CH, THRESHOLD,
+                                                             out_p, cap, cnt_p, stream=s0))
+            tf = float(sum(v.sum() for v in kf.values()))
+            e["frames"] = {"frames_per_rank": B // n, "rank_kernels_us": tf, "speedup": t1 / tf}
+            # templates: the rank's template range, whole build
+            parts = sharding.partition(sharding.coarse_work(ts, ROWS, COLS, T_LEVELS), n)
+            sl.ctx.select_range(*parts[0])
+            kt = kernel_us(sl.run)
+            tt = float(sum(v.sum() for v in kt.values()))
+            e["templates"] = {"templates_per_rank": parts[0][1], "rank_kernels_us": tt, "speedup": t1 / tt}
+            # bands: all n band launches per level run here; a rank's gradient time is its slowest band's
+            kb = kernel_us(lambda: sl.ctx.match_batch_device_banded(d_img.data_ptr(), FRAME_BYTES, B, ROWS, COLS, COLS * CH, CH, THRESHOLD,
+                                                                    sl.d_buf.data_ptr(), cap, n_bands=n, stream=s0))
+            q = kb["k_quantize"].reshape(len(T_LEVELS), n)
+            tq = float(q.max(axis=1).sum())
+            rest = float(sum(v.sum() for k, v in kb.items() if k != "k_quantize"))
+            band_bytes = B * sum((ROWS >> l) * (COLS >> l) for l in range(len(T_LEVELS))) / n
+            tx = XGMI_LATENCY_US + band_bytes / (XGMI_LINK_GBS * 1e3)
+            e["bands"] = {"gradient_us_slowest_band": tq, "gradient_us_per_band": [[round(float(x), 2) for x in r] for r in q],
+                          "other_kernels_us": rest, "all_gather_model_us": tx, "map_bytes_received_per_rank": band_bytes * (n - 1),
+                          "rank_us_exchange_exposed": tq + rest + tx, "speedup_exchange_exposed": t1 / (tq + rest + tx),
+                          "rank_us_exchange_hidden": max(tq + rest, tx), "speedup_exchange_hidden": t1 / max(tq + rest, tx)}
+            sl.ctx.select_range(first, count)
+            strong[str(n)] = e
+        sl.ctx.set_result_mirror(sl.h_buf.data_ptr() + HDR, sl.h_buf.data_ptr())
+        sl.run()
+        fence()
 
     # secondary frames of the default workload: same engine, same templates, other pixels (separately timed)
     extra = {}
@@ -534,7 +634,8 @@ def main():
             "templates_total": total_templates,
             "templates_per_gpu": count,
             "frame": [ROWS, COLS, CH],
-            "parallelism": (f"template-shard x{world}" if wl.shard == "templates" else f"frame-shard x{world}")
+            "parallelism": ((f"row bands of the build x{n_bands} + " if banded else "")
+                            + (f"template-shard x{world}" if wl.shard == "templates" else f"frame-shard x{world}"))
                            + (" + RCCL all-gather of match lists" if collective else ""),
             "frames_per_step": frames_per_step_total,
             "frames_per_step_per_gpu": B,
@@ -549,6 +650,8 @@ def main():
             "matches_distinct": n_matches,
             "coarse_candidates_rank0": n_cand,
         }
+        if strong:
+            cfg["strong_estimate"] = strong
         if extra:
             # the same step on other pixels: the BASELINE configs[1] frame as the reference's demo builds it (the test image
             # on a black canvas: 65 % constant, where the gradient kernel's constant-row shortcut applies -- a best case,

@@ -168,6 +168,24 @@ int sbm_match_batch_device_sharded(sbm_ctx* ctx, const void* d_imgs, int64_t fra
                                    const void* d_mask, float threshold, void* d_local, int64_t cap,
                                    void* d_gathered, void* gathered_mirror, void* stream);
 
+/* Build-sharded step (round 3): the gradient stage is sharded too.  The reference builds the pyramid serially
+ * (line2Dup.cpp:1084-1120) and parallelises only the template loop (:1166-1170); with the pyramid replicated on every
+ * rank a step cannot scale past (build + loop) / build.  Here rank r of a world of n computes ROW BAND r of every
+ * level's orientation map (quantizedOrientations + hysteresisGradient of rows [r, r+1) * rows_l / n, plus the halo
+ * rows the next level's band needs through the fused cv::pyrDown), one grouped in-place ncclAllGather over xGMI
+ * assembles the maps on every rank (1 byte per pixel and level: 1.25 MiB per 1024 x 1024 frame), every rank builds
+ * the linear memories from the assembled maps and matches its template range (sbm_select_range), and the per-rank
+ * match lists are gathered as in sbm_match_batch_device_sharded (same d_local / d_gathered layout).
+ * Needs rows_l % n == 0 with an even quotient at every level, cols % 4 == 0.  The assembled maps are bit for bit the
+ * maps of sbm_match_batch_device (a band's rows depend on rows outside it exactly as in a whole-level launch).
+ * n_bands: 0 or the communicator size with a multi-rank communicator.  On one GPU (no communicator, or a one-rank
+ * one) the call computes all n_bands bands itself, one launch per band and level -- the rehearsal form used by the
+ * tests and by bench.py --banded; d_gathered may then be NULL. */
+int sbm_match_batch_device_banded(sbm_ctx* ctx, const void* d_imgs, int64_t frame_stride, int32_t n_frames,
+                                  int32_t rows, int32_t cols, int32_t stride, int32_t channels, const void* d_mask,
+                                  float threshold, void* d_local, int64_t cap, void* d_gathered,
+                                  void* gathered_mirror, int32_t n_bands, void* stream);
+
 /* Detector::match epilogue (line2Dup.cpp:1142-1145) in canonical form: sort by
  * (similarity desc, template_id asc, class_idx asc, y asc, x asc), drop exact
  * duplicates.  Host-side, in place; returns the new count. */

@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "sbm_set_result_mirror", "sbm_set_graph_mode", "sbm_set_quantize_mode", "sbm_resize_linear",
     "sbm_match_templates_device", "sbm_orientation_bins",
     "sbm_comm_unique_id", "sbm_comm_init", "sbm_comm_destroy", "sbm_match_device_sharded", "sbm_match_batch_device_sharded",
+    "sbm_match_batch_device_banded",
 ]
 
 
@@ -104,6 +105,7 @@ def lib() -> C.CDLL:
     L.sbm_comm_destroy.argtypes = [vp]
     L.sbm_match_device_sharded.argtypes = [vp, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp, vp]
     L.sbm_match_batch_device_sharded.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp, vp]
+    L.sbm_match_batch_device_banded.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp, i32, vp]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
         if name not in ("sbm_last_error", "sbm_destroy", "sbm_canonicalize"):
@@ -243,6 +245,17 @@ class Context:
                                                     C.c_void_p(d_local), cap, C.c_void_p(d_gathered),
                                                     C.c_void_p(gathered_mirror) if gathered_mirror else None,
                                                     C.c_void_p(stream) if stream else None))
+
+    def match_batch_device_banded(self, d_imgs: int, frame_stride: int, n_frames: int, rows: int, cols: int, stride: int,
+                                  channels: int, threshold: float, d_local: int, cap: int, d_gathered: int = 0,
+                                  gathered_mirror: int = 0, n_bands: int = 0, stream: int = 0, d_mask: int = 0):
+        """build-sharded step: this rank's row band of every level's orientation map, grouped in-place all-gather of the
+        bands, linear memories, template loop, gather of the match lists (one GPU: all n_bands bands, one launch each)"""
+        _check(lib().sbm_match_batch_device_banded(self._h, C.c_void_p(d_imgs), frame_stride, n_frames, rows, cols, stride,
+                                                   channels, C.c_void_p(d_mask) if d_mask else None, C.c_float(threshold),
+                                                   C.c_void_p(d_local), cap, C.c_void_p(d_gathered) if d_gathered else None,
+                                                   C.c_void_p(gathered_mirror) if gathered_mirror else None, n_bands,
+                                                   C.c_void_p(stream) if stream else None))
 
     def set_quantize_mode(self, mode: str = "auto", rows_per_wave: int = 0):
         """gradient kernel choice: "auto" (by launch size), "tile" or "stream"; bit-identical results"""

@@ -377,13 +377,17 @@ static int qs_pack_lanes(int rows, int cols, int ch, int frames, int64_t img_fs,
     return lanes;
 }
 
-int quantize_stream_rows(const sbm_ctx* c, int rows, int cols, int ch, int frames, bool wf, int64_t img_fs, int stride)
+// rows = the image's rows; band_rows = the output rows of this launch (rows for a whole level; a row band of a
+// build-sharded step otherwise, which always takes the streaming kernel: the tile kernel has no row-range form)
+int quantize_stream_rows(const sbm_ctx* c, int rows, int cols, int ch, int frames, bool wf, int64_t img_fs, int stride, int band_rows = 0)
 {
+    const bool band = band_rows > 0 && band_rows < rows;
+    const int out_rows = band ? band_rows : rows;
     static const char* env = getenv("SBM_QUANTIZE");
     static const int env_hs = getenv("SBM_QS_HS") ? atoi(getenv("SBM_QS_HS")) : 0;
     const int mode = c->quantize_mode ? c->quantize_mode : (env && !strcmp(env, "tile") ? 1 : (env && !strcmp(env, "stream") ? 2 : 0));
     const int force_hs = c->quantize_hs ? c->quantize_hs : env_hs;
-    if (wf || mode == 1 || cols < 4 || (cols & 3) || (int64_t)rows * cols >= (int64_t)0x7ff00000) return 0;
+    if (wf || (mode == 1 && !band) || cols < 4 || (cols & 3) || (int64_t)rows * cols >= (int64_t)0x7ff00000) return 0;
     const int64_t strips = (cols + QS_USEFUL - 1) / QS_USEFUL;
     if (force_hs > 0) return (force_hs + 1) & ~1;
     // The kernel is bound by vector-instruction issue, and a SIMD needs its full set of resident waves (3 at the
@@ -400,24 +404,26 @@ int quantize_stream_rows(const sbm_ctx* c, int rows, int cols, int ch, int frame
     int64_t best = INT64_MAX;
     // a work item runs whole groups of 7 row iterations (sbm_quantize_stream.h): rows + 10 warm-up / drain, rounded up
     for (int h = 4; h <= 130; h += 2) {
-        const int64_t waves = per_rb * ((rows + h - 1) / h);
-        const int64_t cost = ((waves + slots - 1) / slots) * ((std::min(h, rows) + 10 + 6) / 7 * 7);
+        const int64_t waves = per_rb * ((out_rows + h - 1) / h);
+        const int64_t cost = ((waves + slots - 1) / slots) * ((std::min(h, out_rows) + 10 + 6) / 7 * 7);
         if (cost <= best) best = cost, hs = h;
     }
     // small launches: the 16 x 64 tiles of k_quantize finish sooner than a few long serial chains
-    if (mode != 2 && (int64_t)rows * cols * frames < ((int64_t)4 << 20)) return 0;
+    if (!band && mode != 2 && (int64_t)rows * cols * frames < ((int64_t)4 << 20)) return 0;
     return hs;
 }
 
 int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, int cols, int stride, int ch,
                     const uint8_t* d_mask, float weak, uint8_t* d_out, float* d_mag, float* d_ori, uint8_t* d_pyr,
-                    int frames = 1, int64_t img_fs = 0)
+                    int frames = 1, int64_t img_fs = 0, int row_lo = 0, int row_hi = -1)
 {
+    if (row_hi < 0) row_hi = rows;
+    const bool band = row_lo > 0 || row_hi < rows;
     dim3 grid((cols + QT_C - 1) / QT_C, (rows + QT_R - 1) / QT_R, frames);
     const float thr_sq = weak * weak;
     const bool wf = d_mag || d_ori;
     const int64_t out_fs = (int64_t)rows * cols, pyr_fs = (int64_t)(rows / 2) * (cols / 2) * ch; // the context's own per-frame buffers
-    if (const int hs = quantize_stream_rows(c, rows, cols, ch, frames, wf, img_fs, stride)) {
+    if (const int hs = quantize_stream_rows(c, rows, cols, ch, frames, wf, img_fs, stride, band ? row_hi - row_lo : 0)) {
         QSArgs a;
         memset(&a, 0, sizeof a);
         a.img = d_img;
@@ -432,8 +438,10 @@ int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, i
         a.stride = stride;
         a.thr_i = thr_sq < 2147483000.f ? (int)floorf(thr_sq) : INT_MAX; // mag is an integer: mag > weak^2 <=> mag > floor(weak^2)
         a.hs = hs;
+        a.row_lo = row_lo;
+        a.row_hi = row_hi;
         a.n_strips = (cols + QS_USEFUL - 1) / QS_USEFUL;
-        a.n_rblocks = (rows + hs - 1) / hs;
+        a.n_rblocks = (row_hi - row_lo + hs - 1) / hs;
         a.frames = frames;
         a.pack_lanes = qs_pack_lanes(rows, cols, ch, frames, img_fs, stride);
         a.pack_groups = a.pack_lanes ? (frames + 64 / a.pack_lanes - 1) / (64 / a.pack_lanes) : 0;
@@ -453,6 +461,7 @@ int launch_quantize(sbm_ctx* c, hipStream_t s, const uint8_t* d_img, int rows, i
         HIP_TRY(hipGetLastError());
         return 0;
     }
+    if (band) return fail(SBM_ERR_INVALID, "a row band needs the streaming gradient kernel (cols %% 4 == 0, no float outputs)");
     // many tiles per CU (a batch of frames): 512-thread blocks, four of them per CU; else 1024-thread blocks (tile latency)
     const bool many = (int64_t)grid.x * grid.y * grid.z >= 2048;
 #define SBM_QUANTIZE(CH_, WF_)                                                                                              \
@@ -607,8 +616,36 @@ void lm_form(const sbm_ctx* c, int l, bool* compact, bool* strip)
 // gradient stage + linear memories for every level; d_img0 may be external
 // reset_count != null: the linear-memory launch also zeroes the per-frame counters and *reset_count
 // (c->counters_fresh tells enqueue_coarse to skip its own k_reset launch).
+//
+// Row bands (build-sharded multi-GPU step, sbm_match_batch_device_banded): with bands.n > 1 the gradient stage of
+// level l is launched only for the bands [bands.first, bands.first + bands.count) of bands.n equal row bands, each
+// widened by band_halo(l) rows on either side -- the rows of level l whose fused cv::pyrDown output level l+1's band
+// (itself widened) reads: halo(L-1) = 0, halo(l) = 2 * (halo(l+1) + 5) (7x7 Gaussian 3 + Sobel 1 + vote 1 rows of
+// the next level's image on either side, two source rows each).  bands.between runs after the gradient launches and
+// before the linear memories (the all-gather of the other ranks' bands).
+struct Bands {
+    int n = 1, first = 0, count = 1;
+    int (*between)(sbm_ctx*, hipStream_t, int frames) = nullptr;
+};
+
+int band_halo(int L, int l)
+{
+    int e = 0;
+    for (int k = L - 2; k >= l; --k) e = 2 * (e + 5);
+    return e;
+}
+
+int check_bands(const sbm_ctx* c, int n_bands)
+{
+    if (n_bands < 1) return fail(SBM_ERR_INVALID, "n_bands must be >= 1");
+    for (int l = 0; l < c->L; ++l)
+        if (c->rows[l] % n_bands || ((c->rows[l] / n_bands) & 1))
+            return fail(SBM_ERR_INVALID, "level %d: %d rows do not split into %d bands of an even number of rows", l, c->rows[l], n_bands);
+    return 0;
+}
+
 int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride0, const uint8_t* d_mask0,
-                    int32_t* reset_count = nullptr, int frames = 1, int64_t img0_fs = 0)
+                    int32_t* reset_count = nullptr, int frames = 1, int64_t img0_fs = 0, const Bands* bands = nullptr)
 {
     const int ch = c->channels;
     const uint8_t* img = d_img0;
@@ -631,11 +668,20 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
             img = c->d_img[l].as<uint8_t>();
             stride = c->cols[l] * ch;
         }
-        if (int e = launch_quantize(c, s, img, c->rows[l], c->cols[l], stride, ch, mask, c->cfg.weak_threshold,
-                                    c->d_quant[l].as<uint8_t>(), nullptr, nullptr,
-                                    l + 1 < c->L ? c->d_img[l + 1].as<uint8_t>() : nullptr, frames,
-                                    l == 0 ? img0_fs : (int64_t)c->rows[l] * c->cols[l] * ch))
-            return e;
+        const int nb = bands && bands->n > 1 ? bands->count : 1;
+        for (int b = 0; b < nb; ++b) {
+            int lo = 0, hi = c->rows[l];
+            if (bands && bands->n > 1) {
+                const int br = c->rows[l] / bands->n, e = band_halo(c->L, l);
+                lo = std::max(0, (bands->first + b) * br - e);
+                hi = std::min(c->rows[l], (bands->first + b + 1) * br + e);
+            }
+            if (int e = launch_quantize(c, s, img, c->rows[l], c->cols[l], stride, ch, mask, c->cfg.weak_threshold,
+                                        c->d_quant[l].as<uint8_t>(), nullptr, nullptr,
+                                        l + 1 < c->L ? c->d_img[l + 1].as<uint8_t>() : nullptr, frames,
+                                        l == 0 ? img0_fs : (int64_t)c->rows[l] * c->cols[l] * ch, lo, hi))
+                return e;
+        }
         if (!all_rows && frames > 1) return fail(SBM_ERR_INVALID, "batched match needs T in {4, 8} and 16-column-aligned levels");
         if (!all_rows) {
             if (int e = launch_build_lm(c, s, c->d_quant[l].as<uint8_t>(), c->rows[l], c->cols[l], c->cfg.T[l],
@@ -645,6 +691,8 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
             c->lm_compact[l] = false;
         }
     }
+    if (bands && bands->between)
+        if (int e = bands->between(c, s, frames)) return e;
     if (all_rows) { // every level's linear memories (and the counter reset) in one launch
         LmArgs a;
         memset(&a, 0, sizeof a);
@@ -1755,6 +1803,8 @@ struct Rccl {
     int (*CommInitRank)(void**, int, Id128, int) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
@@ -1770,11 +1820,13 @@ int rccl_load()
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.h, "ncclAllGather");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.h, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.h, "ncclGetErrorString");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(g_rccl.h, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(g_rccl.h, "ncclGroupEnd");
     g_rccl_destroy_hook = [](sbm_ctx* c) {
         if (c->comm) g_rccl.CommDestroy(c->comm);
         c->comm = nullptr;
     };
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
         g_rccl.h = nullptr;
         return fail(SBM_ERR_HIP, "librccl lacks the expected entry points");
     }
@@ -1866,6 +1918,80 @@ extern "C" int sbm_match_batch_device_sharded(sbm_ctx* c, const void* d_imgs, in
         const size_t total = bytes * (size_t)c->comm_world;
         hipLaunchKernelGGL(k_copy_bytes, dim3((unsigned)std::min<size_t>((total / 16 + 255) / 256 + 1, 1024)), dim3(256), 0, s,
                            (const uint8_t*)d_gathered, (uint8_t*)gathered_mirror, total);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+// the exchange of the build-sharded step: every rank's row band of every level's orientation map, in place
+// (rank r's band of frame f already sits at its final address: ncclAllGather with sendbuff = recvbuff + r * count),
+// all frames and levels in one ncclGroup = one fused launch on the kernels' stream
+static int gather_bands(sbm_ctx* c, hipStream_t s, int frames)
+{
+    int rc = g_rccl.GroupStart();
+    if (rc) return fail(SBM_ERR_HIP, "ncclGroupStart: %s", rccl_err(rc));
+    for (int l = 0; l < c->L && !rc; ++l) {
+        const size_t fs = (size_t)c->rows[l] * c->cols[l], cnt = fs / (size_t)c->comm_world;
+        for (int f = 0; f < frames && !rc; ++f) {
+            uint8_t* recv = c->d_quant[l].as<uint8_t>() + (size_t)f * fs;
+            rc = g_rccl.AllGather(recv + (size_t)c->comm_rank * cnt, recv, cnt, /* ncclUint8 */ 1, c->comm, s);
+        }
+    }
+    const int rc2 = g_rccl.GroupEnd();
+    if (rc || rc2) return fail(SBM_ERR_HIP, "ncclAllGather (bands): %s", rccl_err(rc ? rc : rc2));
+    return 0;
+}
+
+extern "C" int sbm_match_batch_device_banded(sbm_ctx* c, const void* d_imgs, int64_t frame_stride, int32_t n_frames, int32_t rows,
+                                             int32_t cols, int32_t stride, int32_t channels, const void* d_mask, float threshold,
+                                             void* d_local, int64_t cap, void* d_gathered, void* gathered_mirror, int32_t n_bands,
+                                             void* stream)
+{
+    if (!c || !d_imgs || !d_local) return fail(SBM_ERR_INVALID, "null argument");
+    if (n_frames < 1) return fail(SBM_ERR_INVALID, "n_frames must be >= 1");
+    if (stride < cols * channels) return fail(SBM_ERR_INVALID, "stride %d < cols*channels", stride);
+    if (n_frames > 1 && frame_stride < (int64_t)stride * rows) return fail(SBM_ERR_INVALID, "frame_stride smaller than one frame");
+    const bool comm = c->comm != nullptr;
+    if (comm && !d_gathered) return fail(SBM_ERR_INVALID, "d_gathered is required with a communicator");
+    const bool multi = comm && c->comm_world > 1;
+    if (multi && n_bands != 0 && n_bands != c->comm_world)
+        return fail(SBM_ERR_INVALID, "n_bands %d != communicator size %d", n_bands, c->comm_world);
+    if (multi) n_bands = c->comm_world;
+    if (n_bands < 1) return fail(SBM_ERR_INVALID, "n_bands must be >= 1 on a single GPU");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const bool dirty = !(c->channels == channels && c->rows[0] == rows && c->cols[0] == cols && c->levels_valid == c->L &&
+                         n_frames <= c->batch) ||
+                       !c->have_thr || memcmp(&threshold, &c->thr_cached, 4) != 0 || c->foff_dirty;
+    if (dirty) HIP_TRY(hipDeviceSynchronize());
+    if (int e = ensure_geometry(c, rows, cols, channels, n_frames)) return e;
+    if (int e = check_bands(c, n_bands)) return e;
+    if (c->profiling && !c->profiling_keep) c->clear_timings();
+    if (int e = prepare_templates(c, s, threshold, cap)) return e;
+    const size_t header = ((size_t)n_frames * 8 + 15) / 16 * 16;
+    const size_t bytes = header + (size_t)n_frames * (size_t)cap * sizeof(sbm_match_rec);
+    sbm_match_rec* out = (sbm_match_rec*)((char*)d_local + header);
+    int32_t* counts = (int32_t*)d_local;
+    Bands b;
+    b.n = n_bands;
+    b.first = multi ? c->comm_rank : 0;  // several ranks: this rank's band, then the exchange
+    b.count = multi ? 1 : n_bands;       // one GPU: every band, one launch each (rehearsal of the band launches; with a
+    b.between = comm ? gather_bands : nullptr; // one-rank communicator also of the grouped in-place all-gathers)
+    // a result mirror set on the context would be written by the last kernel; the gathered mirror below replaces it
+    if (int e = enqueue_pyramid(c, s, (const uint8_t*)d_imgs, stride, (const uint8_t*)d_mask, counts, n_frames, frame_stride, &b)) return e;
+    if (int e = enqueue_coarse(c, s, out, cap, counts, n_frames)) return e;
+    if (int e = enqueue_local(c, s, out, cap, counts, n_frames)) return e;
+    const void* result = d_local;
+    size_t total = bytes;
+    if (comm) { // the second exchange of the step: the per-rank match lists (as sbm_match_batch_device_sharded)
+        int rc = g_rccl.AllGather(d_local, d_gathered, bytes, /* ncclUint8 */ 1, c->comm, s);
+        if (rc) return fail(SBM_ERR_HIP, "ncclAllGather: %s", rccl_err(rc));
+        result = d_gathered;
+        total = bytes * (size_t)c->comm_world;
+    }
+    if (gathered_mirror) {
+        hipLaunchKernelGGL(k_copy_bytes, dim3((unsigned)std::min<size_t>((total / 16 + 255) / 256 + 1, 1024)), dim3(256), 0, s,
+                           (const uint8_t*)result, (uint8_t*)gathered_mirror, total);
         HIP_TRY(hipGetLastError());
     }
     return 0;

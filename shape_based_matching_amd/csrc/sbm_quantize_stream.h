@@ -62,6 +62,11 @@ struct QSArgs {
     int32_t rows, cols, stride;
     int32_t thr_i;       // floor(weak^2): `mag > weak^2` in integers
     int32_t hs;          // output rows per work item (even)
+    // Output rows of this launch: [row_lo, row_hi), 0 .. rows for a whole level.  A row BAND of a level is what one
+    // rank of a build-sharded step computes (sbm_match_batch_device_banded): the band's rows depend on source rows
+    // outside it exactly as they do in a whole-level launch (loads are clamped to the IMAGE, not to the band), so a
+    // level assembled from bands equals the level computed at once.  n_rblocks = ceil((row_hi - row_lo) / hs).
+    int32_t row_lo, row_hi;
     int32_t n_strips, n_rblocks;
     int32_t frames;      // frames of the batch
     // Packed last strip.  The last strip of a row covers cols - 240 (n_strips - 1) columns -- 64 of 1024, 32 of 512 --
@@ -113,12 +118,12 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
     using namespace wv;
     constexpr int ND = CH == 3 ? 3 : 1; // source dwords per lane and row
     const int rows = a.rows, cols = a.cols;
-    // Every work item owns exactly min(hs, rows) output rows: the last row block is moved up to end at the image's last
-    // row (it then recomputes a few rows of the block above -- the same bytes, stored twice).  All items of a launch run
+    // Every work item owns exactly min(hs, row_hi - row_lo) output rows: the last row block is moved up to end at the
+    // launch's last row (it then recomputes a few rows of the block above -- the same bytes, stored twice).  All items of a launch run
     // the same number of row iterations, in whole groups of 7 (see the row loop).
-    int R0 = rb * a.hs;
-    if (R0 + a.hs > rows) R0 = rows > a.hs ? rows - a.hs : 0;
-    const int R1 = R0 + a.hs < rows ? R0 + a.hs : rows;
+    int R0 = a.row_lo + rb * a.hs;
+    if (R0 + a.hs > a.row_hi) R0 = a.row_hi - a.row_lo > a.hs ? a.row_hi - a.hs : a.row_lo;
+    const int R1 = R0 + a.hs < a.row_hi ? R0 + a.hs : a.row_hi;
     const int cb = strip * QS_USEFUL - QS_HALO_LANES * QS_LANE_PX; // column of lane 0, pixel 0
     const uint8_t* img = a.img + (int64_t)frame * a.img_fs;
     uint8_t* out = a.out + (int64_t)frame * a.out_fs;

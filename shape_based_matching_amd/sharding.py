@@ -115,3 +115,46 @@ def all_gather_frame_lists(recs, counts, n_frames: int, group=None):
             raise RuntimeError(f"match list of frame {f} overflowed on rank {rk}: {c[rk, slot].tolist()} cap={cap}")
         out.append(r[rk, slot, : c[rk, slot, 0]].copy())
     return out
+
+
+# ---- build sharding (round 3): row bands of the gradient stage -------------------------------------------------
+# The reference builds the pyramid serially (line2Dup.cpp:1084-1120) and runs only the template loop in parallel
+# (:1166-1170).  Replicating the build on every rank caps the strong scaling of a step at (build + loop) / build, so
+# sbm_match_batch_device_banded shards the build as well: rank r computes row band r of every level's orientation map,
+# an in-place all-gather assembles the maps, every rank builds the linear memories from them.  These helpers mirror
+# the band geometry of the C side (sbm_capi.hip: band_halo, enqueue_pyramid) for tests, bench.py and estimates.
+def band_halo(n_levels: int, level: int) -> int:
+    """Rows of level ``level`` a rank computes beyond its own band, on either side, so that the next level's band
+    (itself widened by its halo) finds its source rows: 0 at the coarsest level, 2 * (halo(l + 1) + 5) below it
+    (7x7 Gaussian 3 + Sobel 1 + vote 1 rows of the next level's image, two rows of this level each; the fused
+    cv::pyrDown loads its own 5-row window)."""
+    e = 0
+    for _ in range(n_levels - 2, level - 1, -1):
+        e = 2 * (e + 5)
+    return e
+
+
+def band_plan(rows: int, n_levels: int, n_bands: int, band: int) -> List[Tuple[int, int, int, int]]:
+    """Per level (own_lo, own_hi, launch_lo, launch_hi): the rows rank ``band`` owns (and contributes to the gather)
+    and the rows its gradient launch covers.  Needs rows_l % n_bands == 0 with an even quotient at every level."""
+    out = []
+    for l in range(n_levels):
+        r = rows >> l
+        if r % n_bands or (r // n_bands) & 1:
+            raise ValueError(f"level {l}: {r} rows do not split into {n_bands} bands of an even number of rows")
+        br, e = r // n_bands, band_halo(n_levels, l)
+        out.append((band * br, (band + 1) * br, max(0, band * br - e), min(r, (band + 1) * br + e)))
+    return out
+
+
+def all_gather_bands(own_rows, group=None):
+    """Assemble a level's orientation map from the ranks' bands: ``own_rows`` is this rank's torch uint8 tensor
+    ``[frames, band_rows, cols]``; returns ``[frames, world * band_rows, cols]`` (the layout the library's in-place
+    grouped ncclAllGather leaves in HBM)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(own_rows) for _ in range(world)]
+    dist.all_gather(parts, own_rows.contiguous(), group=group)
+    return torch.cat(parts, dim=1)

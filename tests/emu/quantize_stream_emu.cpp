@@ -22,6 +22,8 @@ extern "C" int sbm_emu_quantize_stream(const uint8_t* img, int rows, int cols, i
     const float thr_sq = weak * weak;
     a.thr_i = thr_sq < 2147483000.f ? (int)floorf(thr_sq) : INT_MAX;
     a.hs = hs;
+    a.row_lo = 0;
+    a.row_hi = rows;
     a.n_strips = (cols + sbm::QS_USEFUL - 1) / sbm::QS_USEFUL;
     a.n_rblocks = (rows + hs - 1) / hs;
     a.frames = 1;
@@ -52,6 +54,8 @@ extern "C" int sbm_emu_quantize_stream_batch(const uint8_t* img, int frames, int
     const float thr_sq = weak * weak;
     a.thr_i = thr_sq < 2147483000.f ? (int)floorf(thr_sq) : INT_MAX;
     a.hs = hs;
+    a.row_lo = 0;
+    a.row_hi = rows;
     a.n_strips = (cols + sbm::QS_USEFUL - 1) / sbm::QS_USEFUL;
     a.n_rblocks = (rows + hs - 1) / hs;
     a.frames = frames;
@@ -62,4 +66,34 @@ extern "C" int sbm_emu_quantize_stream_batch(const uint8_t* img, int frames, int
         else sbm::quantize_stream_item<1>(a, item);
     }
     return a.pack_lanes;
+}
+
+// one row band [row_lo, row_hi) of a level (what a rank of the build-sharded step launches): writes only that band's rows
+// of `out` and the pyrDown rows [row_lo / 2, row_hi / 2) of `pyr`
+extern "C" int sbm_emu_quantize_stream_band(const uint8_t* img, int rows, int cols, int stride, int ch, const uint8_t* mask,
+                                            float weak, uint8_t* out, uint8_t* pyr, int hs, int row_lo, int row_hi)
+{
+    if ((ch != 1 && ch != 3) || cols < 4 || (cols & 3) || rows < 1 || hs < 2 || (hs & 1)) return -1;
+    if (row_lo < 0 || row_hi > rows || row_lo >= row_hi || (row_lo & 1)) return -1;
+    sbm::QSArgs a{};
+    a.img = img;
+    a.mask = mask;
+    a.out = out;
+    a.pyr = pyr;
+    a.rows = rows;
+    a.cols = cols;
+    a.stride = stride;
+    const float thr_sq = weak * weak;
+    a.thr_i = thr_sq < 2147483000.f ? (int)floorf(thr_sq) : INT_MAX;
+    a.hs = hs;
+    a.row_lo = row_lo;
+    a.row_hi = row_hi;
+    a.n_strips = (cols + sbm::QS_USEFUL - 1) / sbm::QS_USEFUL;
+    a.n_rblocks = (row_hi - row_lo + hs - 1) / hs;
+    a.frames = 1;
+    for (int item = 0; item < sbm::quantize_stream_items(a); ++item) {
+        if (ch == 3) sbm::quantize_stream_item<3>(a, item);
+        else sbm::quantize_stream_item<1>(a, item);
+    }
+    return 0;
 }

@@ -3,7 +3,7 @@ hipGraph mode and plain-stream mode, with and without the pinned-host result mir
 import numpy as np
 import pytest
 
-from shape_based_matching_amd import synth
+from shape_based_matching_amd import capi, synth
 from shape_based_matching_amd.templates import MATCH_DTYPE
 
 pytestmark = pytest.mark.gpu
@@ -466,3 +466,70 @@ def test_match_batch_device_graph_replay(oracle, ctx_factory, case1):
             order = [2, 3, 0, 1]  # same buffers, other pixels: the replayed graph reads the buffer, not a snapshot
             d_imgs.copy_(torch.from_numpy(np.stack([frames[i] for i in order])).to(dev))
             run_and_check(order, mirror)
+
+
+@pytest.mark.parametrize("with_comm", [False, True])
+def test_match_batch_device_banded_equals_whole_level_build(oracle, ctx_factory, case1, with_comm):
+    """Round 3, build-sharded step on one GPU: the gradient stage launched band by band (2, 4 and 8 row bands, each widened
+    by the halo the next level needs) leaves the orientation maps and linear memories of the whole-level build, and the
+    match lists of sbm_match_batch_device; with a one-rank communicator the grouped in-place ncclAllGather of the bands
+    and the gather of the lists run as well.  BGR and gray, a mask, a frame whose constant canvas crosses band borders."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    ts = case1["templates"].subset(range(300, 361, 3))
+    base = synth.embed(case1["test"], 640, 768, 80, 80)
+    frames = np.stack([base, np.ascontiguousarray(base[:, ::-1]), np.roll(base, 40, axis=1), synth.scene_with_object(5, 640, 768, case1["test"][:473, :600])])
+    B, rows, cols = frames.shape[:3]
+    cap, rec = 512, MATCH_DTYPE.itemsize
+    hdr = (8 * B + 15) // 16 * 16
+    nbytes = hdr + B * cap * rec
+    stream = torch.cuda.Stream(device=dev)
+    wants = []
+    for fr in frames:
+        p = oracle.Pyramid.build(fr, [4, 8], 30.0)
+        wants.append((p.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 85.0), p.quantized(0), p.quantized(1), p.lm(1)))
+        p.free()
+    assert sum(len(w[0]) for w in wants) > 0
+    for ch in (3, 1):
+        ctx = ctx_factory()
+        ctx.upload_templates(ts)
+        if with_comm:
+            ctx.comm_init(1, 0, ctx.comm_unique_id())
+        fr_in = frames if ch == 3 else np.ascontiguousarray(frames[..., 1])
+        d_imgs = torch.from_numpy(fr_in).to(dev)
+        fs = rows * cols * ch
+        for n_bands in (1, 2, 4, 8):
+            d_local = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            d_gath = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            h_gath = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+            torch.cuda.synchronize()
+            ctx.match_batch_device_banded(d_imgs.data_ptr(), fs, B, rows, cols, cols * ch, ch, 85.0, d_local.data_ptr(), cap,
+                                          d_gathered=d_gath.data_ptr() if with_comm else 0, gathered_mirror=h_gath.data_ptr(),
+                                          n_bands=n_bands, stream=stream.cuda_stream)
+            stream.synchronize()
+            if ch == 3:  # frame 0 of the batch is what the stage read-backs return
+                assert np.array_equal(ctx.get_quantized(0), wants[0][1]) and np.array_equal(ctx.get_quantized(1), wants[0][2]), n_bands
+                assert np.array_equal(ctx.get_linear_memories(1), wants[0][3]), n_bands
+            bufs = [d_local.cpu().numpy(), h_gath.numpy()] + ([d_gath.cpu().numpy()] if with_comm else [])
+            # the reference for gray frames: the same engine's whole-level batch call
+            if ch == 1:
+                d_ref = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+                ctx.match_batch_device(d_imgs.data_ptr(), fs, B, rows, cols, cols, 1, 85.0, d_ref.data_ptr() + hdr, cap, d_ref.data_ptr(),
+                                       stream=stream.cuda_stream)
+                stream.synchronize()
+                ref = d_ref.cpu().numpy()
+            for buf in bufs:
+                cnt = buf[: 8 * B].view(np.int32).reshape(B, 2)
+                for f in range(B):
+                    got = buf[hdr + f * cap * rec: hdr + (f + 1) * cap * rec].view(MATCH_DTYPE)[: cnt[f, 0]]
+                    if ch == 3:
+                        assert cnt[f, 1] == 0 and cnt[f, 0] == len(wants[f][0]), (n_bands, f)
+                        assert key(got) == key(wants[f][0]), (n_bands, f)
+                    else:
+                        rc = ref[: 8 * B].view(np.int32).reshape(B, 2)
+                        assert cnt[f].tolist() == rc[f].tolist()
+                        assert key(got) == key(ref[hdr + f * cap * rec: hdr + (f + 1) * cap * rec].view(MATCH_DTYPE)[: rc[f, 0]])
+        with pytest.raises(capi.SbmError):  # 640 rows do not split into 3 bands
+            ctx.match_batch_device_banded(d_imgs.data_ptr(), fs, B, rows, cols, cols * ch, ch, 85.0, d_local.data_ptr(), cap,
+                                          d_gathered=d_gath.data_ptr() if with_comm else 0, n_bands=3, stream=stream.cuda_stream)
