@@ -212,9 +212,28 @@ public:
     void readClasses(const std::vector<std::string>& class_ids, const std::string& format = "templates_%s.yml.gz");
     void writeClasses(const std::string& format = "templates_%s.yml.gz") const;
 
-    /* MI355X extensions (not in the reference): GPU ordinal for this detector's
-     * context, and the pre-dedup multiset of the last match() for parity checks. */
+    /* ---- MI355X extensions (not in the reference) ----
+     * setDevice: GPU ordinal of this detector's engine context.
+     * setDevices: several GPUs in ONE process -- one engine context and one host thread per listed device (an ordinal
+     *   may be listed more than once).  match() then shards the selected templates over them (work-balanced contiguous
+     *   ranges) and concatenates the lists, as the reference's OpenMP team over templates does (line2Dup.cpp:1166-1170);
+     *   matchBatch() deals the frames over them instead.
+     * matchBatch: a batch of frames of one size and type; element f is exactly what match(sources[f], ...) returns.  The
+     *   frames are uploaded in sub-batches while the kernels of the previous sub-batch run (sbm_match_batch_host).
+     * matchAsync / wait: the same, split: matchAsync enqueues uploads and kernels and returns, wait() returns the lists.
+     *   The frames must stay alive and unchanged until wait(); one batch in flight per detector.
+     * pinBuffer / unpinBuffer: page-lock a frame buffer the caller re-uses (a camera loop), so that its uploads are
+     *   direct DMAs; explicit because the detector cannot know the buffer's lifetime (sbm_pin_host_buffer). */
     void setDevice(int device_id);
+    void setDevices(const std::vector<int>& device_ids);
+    std::vector<std::vector<Match>> matchBatch(const std::vector<cv::Mat>& sources, float threshold,
+                                               const std::vector<std::string>& class_ids = std::vector<std::string>(),
+                                               const cv::Mat mask = cv::Mat()) const;
+    void matchAsync(const std::vector<cv::Mat>& sources, float threshold,
+                    const std::vector<std::string>& class_ids = std::vector<std::string>(), const cv::Mat mask = cv::Mat()) const;
+    std::vector<std::vector<Match>> wait() const;
+    void pinBuffer(const cv::Mat& frame) const;
+    void unpinBuffer(const cv::Mat& frame) const;
 
 protected:
     cv::Ptr<ColorGradient> modality;
@@ -228,17 +247,33 @@ protected:
     static Detector* instance;
 
 private:
-    /* device side: one sbm_ctx, templates re-uploaded when class_templates changed */
+    /* device side: one sbm_ctx per device (ctx_ = the first), templates re-uploaded when class_templates changed */
     mutable sbm_ctx* ctx_;
+    mutable std::vector<sbm_ctx*> ctxs_;
     mutable bool templates_dirty_;
     mutable std::vector<std::string> uploaded_class_order_;
+    mutable std::vector<int32_t> uploaded_class_of_; /* class index of every uploaded template, upload order */
     mutable std::vector<int32_t> selected_;   /* class selection currently active in the engine (match() caches it) */
     mutable bool selection_valid_ = false;
+    mutable int selection_mode_ = 0;          /* 0: every context holds the whole selection; 1: sharded over the contexts */
+    mutable int selection_rows_ = 0, selection_cols_ = 0; /* geometry the shards were balanced for */
     mutable std::vector<unsigned char> recs_;  /* match record scratch, kept between calls */
     int device_id_;
+    std::vector<int> device_ids_;
+    /* batch in flight (matchAsync): frames per context, capacity, result scratch */
+    struct AsyncState {
+        bool active = false;
+        std::vector<int> first, count; /* frame range of every context */
+        int64_t cap = 0;
+        size_t n_frames = 0;
+    };
+    mutable AsyncState async_;
     void ensureContext() const;
     void uploadTemplates() const;
     void dropContext();
+    /* returns false when the class selection is empty (nothing to match) */
+    bool prepare(const std::vector<std::string>& class_ids, int rows, int cols, bool sharded) const;
+    std::vector<Match> toMatches(const void* recs, int64_t n) const;
 };
 
 } // namespace line2Dup

@@ -76,6 +76,15 @@ int sbm_upload_templates(sbm_ctx* ctx, int32_t n_templates, const sbm_template_l
 int sbm_select_classes(sbm_ctx* ctx, const int32_t* class_idx, int32_t n);
 int sbm_select_range(sbm_ctx* ctx, int32_t first, int32_t count);
 
+/* An explicit list of template indices (upload order) as the active set: what sbm_select_classes / sbm_select_range
+ * build internally; used to shard a class selection over several GPUs. */
+int sbm_select_templates(sbm_ctx* ctx, const int32_t* template_idx, int32_t n);
+/* Contiguous, work-balanced shards of a template list for a rows x cols frame: the list is template_idx[0..n) (NULL:
+ * every uploaded template in upload order); shard s is list[first[s] .. first[s] + count[s]).  Work = byte-adds of the
+ * coarse pass (in-bounds coarsest-level features x template_positions, line2Dup.cpp:818-837). */
+int sbm_partition_templates(sbm_ctx* ctx, int32_t rows, int32_t cols, const int32_t* template_idx, int32_t n,
+                            int32_t n_shards, int32_t* first, int32_t* count);
+
 /* ---- whole hot path -----------------------------------------------------
  * Detector::match (line2Dup.cpp:1078-1150) without the final std::sort /
  * std::unique: emits the pre-dedup multiset of matches in unspecified order;
@@ -87,6 +96,41 @@ int sbm_select_range(sbm_ctx* ctx, int32_t first, int32_t count);
 int sbm_match(sbm_ctx* ctx, const uint8_t* img_host, int32_t rows, int32_t cols, int32_t stride,
               int32_t channels, const uint8_t* mask_host, float threshold, sbm_match_rec* out_host,
               int64_t cap, int64_t* n_out);
+
+/* Single-process multi-GPU form of sbm_match: one context per GPU (all holding the same templates, each with its own
+ * selection -- sbm_partition_templates + sbm_select_range / sbm_select_templates), one host thread per context, the
+ * frame uploaded to every GPU, the per-GPU lists concatenated on the host: the reference's OpenMP team over
+ * templates with its concatenating reduction (line2Dup.cpp:1166-1170).  One process per GPU + RCCL is the other
+ * multi-GPU form (sbm_comm_* below).  Several contexts on ONE GPU are allowed (tests). */
+int sbm_match_sharded(sbm_ctx* const* ctxs, int32_t n_ctx, const uint8_t* img_host, int32_t rows, int32_t cols,
+                      int32_t stride, int32_t channels, const uint8_t* mask_host, float threshold,
+                      sbm_match_rec* out_host, int64_t cap, int64_t* n_out);
+
+/* A batch of frames from HOST memory, pipelined (streaming API with asynchronous upload overlap; the
+ * reference calls Detector::match once per frame, line2Dup.cpp:1078): the frames travel over PCIe in sub-batches of
+ * `sub_batch` frames (0 = 8) on a copy stream into one of two device buffers while the kernels of the previous
+ * sub-batch run; every kernel is launched once per sub-batch (as in sbm_match_batch_device); the lists arrive in a
+ * pinned host block written by the last kernel.  frames[f] points to frame f (rows x stride bytes).  Results: the
+ * records of frame f at out + f * cap, {n_matches, overflow} at counts + 2 * f.  _begin enqueues everything and
+ * returns (uploads from memory that is not pinned are staged by the runtime and may block meanwhile); _end waits and
+ * copies the lists out; one batch in flight per context.  SBM_ERR_CAPACITY if a frame has more than cap matches (its
+ * first cap records are still returned). */
+int sbm_match_batch_host_begin(sbm_ctx* ctx, const uint8_t* const* frames, int32_t n_frames, int32_t rows, int32_t cols,
+                               int32_t stride, int32_t channels, const uint8_t* mask_host, float threshold, int64_t cap,
+                               int32_t sub_batch);
+int sbm_match_batch_host_end(sbm_ctx* ctx, sbm_match_rec* out_host, int32_t* counts);
+int sbm_match_batch_host(sbm_ctx* ctx, const uint8_t* const* frames, int32_t n_frames, int32_t rows, int32_t cols,
+                         int32_t stride, int32_t channels, const uint8_t* mask_host, float threshold,
+                         sbm_match_rec* out_host, int64_t cap, int32_t* counts, int32_t sub_batch);
+
+/* Optional: pin a caller-owned host buffer (hipHostRegister) so that sbm_match / sbm_build_pyramid upload frames that
+ * lie inside it with one asynchronous DMA instead of the runtime's staged pageable copy (a camera loop that re-uses
+ * its frame buffer: 115 instead of ~160 us per 1024 x 1024 BGR match).  Explicit by design -- the library never pins
+ * memory it was merely handed: the caller must keep the range mapped until sbm_unpin_host_buffer (or sbm_destroy)
+ * and must not free / re-map it while pinned.  Buffers the caller pinned itself (hipHostMalloc, hipHostRegister)
+ * need neither call.  sbm_unpin_host_buffer waits for the context's stream first. */
+int sbm_pin_host_buffer(sbm_ctx* ctx, const void* host_ptr, int64_t bytes);
+int sbm_unpin_host_buffer(sbm_ctx* ctx, const void* host_ptr);
 
 /* Same path with the frame already resident in HBM.  Asynchronous: enqueues
  * every kernel on `stream` and returns.  Results go to caller-provided device

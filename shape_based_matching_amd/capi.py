@@ -29,7 +29,9 @@ ABI_SYMBOLS = [
     "sbm_set_result_mirror", "sbm_set_graph_mode", "sbm_set_quantize_mode", "sbm_resize_linear",
     "sbm_match_templates_device", "sbm_orientation_bins",
     "sbm_comm_unique_id", "sbm_comm_init", "sbm_comm_destroy", "sbm_match_device_sharded", "sbm_match_batch_device_sharded",
-    "sbm_match_batch_device_banded",
+    "sbm_match_batch_device_banded", "sbm_pin_host_buffer", "sbm_unpin_host_buffer",
+    "sbm_select_templates", "sbm_partition_templates", "sbm_match_sharded",
+    "sbm_match_batch_host", "sbm_match_batch_host_begin", "sbm_match_batch_host_end",
 ]
 
 
@@ -105,6 +107,14 @@ def lib() -> C.CDLL:
     L.sbm_comm_destroy.argtypes = [vp]
     L.sbm_match_device_sharded.argtypes = [vp, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp, vp]
     L.sbm_match_batch_device_sharded.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp, vp]
+    L.sbm_select_templates.argtypes = [vp, vp, i32]
+    L.sbm_partition_templates.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp]
+    L.sbm_match_sharded.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, f32, vp, i64, C.POINTER(i64)]
+    L.sbm_match_batch_host_begin.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, f32, i64, i32]
+    L.sbm_match_batch_host_end.argtypes = [vp, vp, vp]
+    L.sbm_match_batch_host.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, f32, vp, i64, vp, i32]
+    L.sbm_pin_host_buffer.argtypes = [vp, vp, i64]
+    L.sbm_unpin_host_buffer.argtypes = [vp, vp]
     L.sbm_match_batch_device_banded.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp, i32, vp]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
@@ -256,6 +266,56 @@ class Context:
                                                    C.c_void_p(d_local), cap, C.c_void_p(d_gathered) if d_gathered else None,
                                                    C.c_void_p(gathered_mirror) if gathered_mirror else None, n_bands,
                                                    C.c_void_p(stream) if stream else None))
+
+    def select_templates(self, idx: Sequence[int]):
+        a = np.ascontiguousarray(idx, np.int32)
+        _check(lib().sbm_select_templates(self._h, _p(a), len(a)))
+
+    def partition_templates(self, rows: int, cols: int, n_shards: int, idx: Optional[Sequence[int]] = None):
+        """work-balanced contiguous shards [(first, count)] of the template list ``idx`` (None: all, upload order)"""
+        a = None if idx is None else np.ascontiguousarray(idx, np.int32)
+        first = np.zeros(n_shards, np.int32)
+        count = np.zeros(n_shards, np.int32)
+        _check(lib().sbm_partition_templates(self._h, rows, cols, _p(a), 0 if a is None else len(a), n_shards, _p(first), _p(count)))
+        return list(zip(first.tolist(), count.tolist()))
+
+    @staticmethod
+    def match_sharded(ctxs: Sequence["Context"], img: np.ndarray, threshold: float, mask: Optional[np.ndarray] = None,
+                      cap: int = 1 << 16) -> np.ndarray:
+        """single-process multi-GPU match: one context (and host thread) per GPU, lists concatenated on the host"""
+        img, r, c, ch = _img(img)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        hs = (C.c_void_p * len(ctxs))(*[x._h for x in ctxs])
+        out = np.zeros(cap, MATCH_DTYPE)
+        n = C.c_int64(0)
+        _check(lib().sbm_match_sharded(hs, len(ctxs), _p(img), r, c, c * ch, ch, _p(m), C.c_float(threshold), _p(out), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def match_batch_host(self, frames: Sequence[np.ndarray], threshold: float, cap: int = 1024, sub_batch: int = 0,
+                         mask: Optional[np.ndarray] = None, split: bool = False):
+        """frames in host memory, pipelined uploads; returns a list of record arrays (one per frame).
+        split=True: sbm_match_batch_host_begin, then _end (the asynchronous form)"""
+        arrs = [_img(f) for f in frames]
+        r, c, ch = arrs[0][1:]
+        assert all(a[1:] == (r, c, ch) for a in arrs)
+        ptrs = (C.c_void_p * len(arrs))(*[a[0].ctypes.data for a in arrs])
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        out = np.zeros((len(arrs), cap), MATCH_DTYPE)
+        counts = np.zeros((len(arrs), 2), np.int32)
+        if split:
+            _check(lib().sbm_match_batch_host_begin(self._h, ptrs, len(arrs), r, c, c * ch, ch, _p(m), C.c_float(threshold), cap, sub_batch))
+            _check(lib().sbm_match_batch_host_end(self._h, _p(out), _p(counts)))
+        else:
+            _check(lib().sbm_match_batch_host(self._h, ptrs, len(arrs), r, c, c * ch, ch, _p(m), C.c_float(threshold), _p(out), cap,
+                                              _p(counts), sub_batch))
+        return [out[f, : counts[f, 0]].copy() for f in range(len(arrs))]
+
+    def pin_host_buffer(self, a: np.ndarray):
+        """explicit opt-in: frames inside ``a`` are uploaded by direct DMA until unpin_host_buffer(a) / close()"""
+        _check(lib().sbm_pin_host_buffer(self._h, C.c_void_p(a.ctypes.data), a.nbytes))
+
+    def unpin_host_buffer(self, a: np.ndarray):
+        _check(lib().sbm_unpin_host_buffer(self._h, C.c_void_p(a.ctypes.data)))
 
     def set_quantize_mode(self, mode: str = "auto", rows_per_wave: int = 0):
         """gradient kernel choice: "auto" (by launch size), "tile" or "stream"; bit-identical results"""

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sbm.h"
@@ -137,20 +138,29 @@ struct sbm_ctx {
     sbm_match_rec* mirror_out = nullptr; // optional device-visible mirror of the results (sbm_set_result_mirror)
     int32_t* mirror_count = nullptr;
     // host entry point (sbm_match): pinned result buffer the last kernel writes into (no device-to-host copy, one
-    // synchronisation per call) and a small cache of caller frame buffers pinned with hipHostRegister, so that the
-    // frame upload of a caller that re-uses its buffer (a camera loop) is one asynchronous DMA instead of a staged
-    // pageable copy
+    // synchronisation per call).  Caller frame buffers are pinned only on request (sbm_pin_host_buffer): the upload of
+    // a frame inside such a range is one asynchronous DMA; any other host pointer takes the runtime's pageable path.
     sbm_match_rec* h_res = nullptr;
     int32_t* h_res_count = nullptr;
     int64_t h_res_cap = 0;
-    struct PinnedFrame {
-        const void* p = nullptr;
-        size_t bytes = 0;
-        int seen = 0;
-        bool registered = false;
-        uint64_t last_use = 0;
-    } pinned[4];
-    uint64_t pin_clock = 0;
+    struct PinnedRange {
+        const uint8_t* p;
+        size_t bytes;
+    };
+    std::vector<PinnedRange> pinned; // ranges THIS context registered and has not yet unregistered
+    // host batch pipeline (sbm_match_batch_host_begin / _end): frames travel over PCIe on copy_stream into one of two
+    // device input buffers while the kernels of the previous sub-batch run on `stream`; every sub-batch's match lists
+    // land in one pinned host block through the result mirror
+    hipStream_t copy_stream = nullptr;
+    DevBuf d_in[2], d_bout;
+    hipEvent_t ev_up[2] = {}, ev_free[2] = {};
+    uint8_t* h_bout = nullptr;
+    size_t h_bout_bytes = 0;
+    struct {
+        bool active = false;
+        int n_frames = 0;
+        int64_t cap = 0;
+    } pending;
     DevBuf d_scratch;
 
     // hipGraph cache for sbm_match_device (one captured graph per distinct argument tuple)
@@ -1004,8 +1014,16 @@ void sbm_destroy(sbm_ctx* c)
     (void)hipSetDevice(c->cfg.device_id);
     (void)hipDeviceSynchronize();
     if (c->comm && g_rccl_destroy_hook) g_rccl_destroy_hook(c);
-    for (auto& pf : c->pinned)
-        if (pf.registered) (void)hipHostUnregister((void*)pf.p);
+    for (auto& pr : c->pinned) (void)hipHostUnregister((void*)pr.p); // the caller never unpinned them: still registered by us
+    c->pinned.clear();
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]);
+        if (c->ev_free[i]) (void)hipEventDestroy(c->ev_free[i]);
+        c->d_in[i].release();
+    }
+    c->d_bout.release();
+    if (c->h_bout) (void)hipHostFree(c->h_bout);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->h_res_count) (void)hipHostFree(c->h_res_count);
     c->drop_graphs();
@@ -1163,6 +1181,60 @@ int sbm_select_range(sbm_ctx* c, int32_t first, int32_t count)
     std::vector<int32_t> act(count);
     for (int i = 0; i < count; ++i) act[i] = first + i;
     return set_active(c, act);
+}
+
+int sbm_select_templates(sbm_ctx* c, const int32_t* idx, int32_t n)
+{
+    if (!c || n < 0 || (n && !idx)) return fail(SBM_ERR_INVALID, "bad template list");
+    std::vector<int32_t> act(idx, idx + n);
+    for (int32_t t : act)
+        if (t < 0 || t >= c->n_templates) return fail(SBM_ERR_INVALID, "template index %d out of range", t);
+    return set_active(c, act);
+}
+
+int sbm_partition_templates(sbm_ctx* c, int32_t rows, int32_t cols, const int32_t* idx, int32_t n, int32_t n_shards, int32_t* first,
+                            int32_t* count)
+{
+    if (!c || n_shards < 1 || !first || !count || n < 0 || rows <= 0 || cols <= 0) return fail(SBM_ERR_INVALID, "bad partition arguments");
+    // the template list to divide: idx[0..n) if given, else every uploaded template in upload order
+    std::vector<int32_t> list;
+    if (idx) list.assign(idx, idx + n);
+    else {
+        list.resize(c->n_templates);
+        for (int t = 0; t < c->n_templates; ++t) list[t] = t;
+    }
+    const int L = c->L, lc = L - 1, T = c->cfg.T[lc];
+    const int rl = rows >> lc, cl = cols >> lc, W = cl / T, H = rl / T;
+    // work of a template = byte-adds of its coarse pass (in-bounds features x template_positions, line2Dup.cpp:818-837);
+    // at least 1 so that templates without work still spread out
+    std::vector<double> cum(list.size() + 1, 0.0);
+    for (size_t i = 0; i < list.size(); ++i) {
+        const int32_t t = list[i];
+        if (t < 0 || t >= c->n_templates) return fail(SBM_ERR_INVALID, "template index %d out of range", t);
+        const DevTL& tl = c->h_tls[(size_t)t * L + lc];
+        const int wf = (tl.width - 1) / T + 1, hf = (tl.height - 1) / T + 1;
+        const int npos = (H - hf) * W + (W - wf) + 1;
+        int64_t inb = 0;
+        if (npos > 0)
+            for (int k = 0; k < tl.nf; ++k) {
+                const uint32_t xy = c->h_fxy[tl.feat_off + k];
+                if ((int)(xy & 0xffff) < cl && (int)(xy >> 16) < rl) ++inb;
+            }
+        cum[i + 1] = cum[i] + std::max<double>(1.0, (double)inb * std::max(npos, 0));
+    }
+    int prev = 0;
+    for (int sh = 0; sh < n_shards; ++sh) {
+        int end = (int)list.size();
+        if (sh + 1 < n_shards) {
+            const double target = cum.back() * (sh + 1) / n_shards;
+            end = (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+            end = std::min(std::max(end, prev), (int)list.size());
+        }
+        first[sh] = prev;
+        count[sh] = end - prev;
+        prev = end;
+    }
+    return 0;
 }
 
 int sbm_match_device(sbm_ctx* c, const void* d_img, int32_t rows, int32_t cols, int32_t stride, int32_t channels,
@@ -1330,30 +1402,164 @@ static int upload_image(sbm_ctx* c, const uint8_t* img, int rows, int cols, int 
     if (!img) return fail(SBM_ERR_INVALID, "null image");
     if (stride < cols * ch) return fail(SBM_ERR_INVALID, "stride %d < cols*channels", stride);
     if (int e = ensure_geometry(c, rows, cols, ch)) return e;
-    { // pin a frame buffer the caller keeps handing in (second sighting): the copy below then is a plain DMA
-        const size_t bytes = (size_t)stride * (rows - 1) + (size_t)cols * ch;
-        sbm_ctx::PinnedFrame* hit = nullptr;
-        sbm_ctx::PinnedFrame* lru = &c->pinned[0];
-        for (auto& pf : c->pinned) {
-            if (pf.p == img && pf.bytes == bytes) hit = &pf;
-            if (pf.last_use < lru->last_use) lru = &pf;
-        }
-        if (!hit) {
-            if (lru->registered) (void)hipHostUnregister((void*)lru->p);
-            *lru = sbm_ctx::PinnedFrame();
-            lru->p = img;
-            lru->bytes = bytes;
-            hit = lru;
-        }
-        hit->last_use = ++c->pin_clock;
-        if (!hit->registered && ++hit->seen == 2 && bytes >= (1u << 16)) {
-            if (hipHostRegister((void*)img, bytes, hipHostRegisterDefault) == hipSuccess) hit->registered = true;
-            else (void)hipGetLastError(); // not pinnable (e.g. read-only mapping): keep the pageable path
-        }
-    }
+    // No implicit pinning: whether the copy below is a direct DMA (the frame lies in memory the caller pinned with
+    // sbm_pin_host_buffer / hipHostMalloc / hipHostRegister) or a staged pageable copy is decided by the runtime from
+    // the pointer's current attributes, never from a cache of addresses seen before.
     HIP_TRY(hipMemcpy2DAsync(c->d_img[0].p, (size_t)cols * ch, img, stride, (size_t)cols * ch, rows, hipMemcpyHostToDevice, c->stream));
     if (mask) HIP_TRY(hipMemcpyAsync(c->d_mask[0].p, mask, (size_t)rows * cols, hipMemcpyHostToDevice, c->stream));
     return 0;
+}
+
+int sbm_match_batch_host_begin(sbm_ctx* c, const uint8_t* const* frames, int32_t n_frames, int32_t rows, int32_t cols, int32_t stride,
+                               int32_t channels, const uint8_t* mask, float threshold, int64_t cap, int32_t sub_batch)
+{
+    if (!c || !frames || n_frames < 1 || cap < 1) return fail(SBM_ERR_INVALID, "bad batch arguments");
+    if (c->pending.active) return fail(SBM_ERR_STATE, "a host batch is already in flight (call sbm_match_batch_host_end)");
+    if (stride < cols * channels) return fail(SBM_ERR_INVALID, "stride %d < cols*channels", stride);
+    for (int f = 0; f < n_frames; ++f)
+        if (!frames[f]) return fail(SBM_ERR_INVALID, "frame %d is null", f);
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    int sub = std::max(1, std::min(sub_batch > 0 ? sub_batch : 8, n_frames));
+    HIP_TRY(hipDeviceSynchronize()); // geometry / template state may change below
+    if (int e = ensure_geometry(c, rows, cols, channels, sub)) return e;
+    // geometries the one-launch linear-memory builder does not take (level widths that are not multiples of 16, other
+    // strides): one frame per "sub-batch" through the generic kernels -- the uploads still overlap the kernels
+    for (int l = 0; l < c->L; ++l)
+        if (!lm_rows_ok(c->d_quant[l].as<uint8_t>(), c->cols[l], c->cfg.T[l])) sub = 1;
+    if (!c->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming));
+        }
+    }
+    const size_t frame_bytes = (size_t)rows * cols * channels;
+    for (int i = 0; i < 2; ++i)
+        if (int e = c->d_in[i].ensure((size_t)sub * frame_bytes)) return e;
+    // results: n_frames blocks of cap records, then n_frames {n_matches, overflow} pairs -- on the device and in pinned memory
+    const size_t rec_bytes = (size_t)n_frames * (size_t)cap * sizeof(sbm_match_rec), total = rec_bytes + (size_t)n_frames * 8;
+    if (int e = c->d_bout.ensure(total)) return e;
+    if (total > c->h_bout_bytes) {
+        if (c->h_bout) (void)hipHostFree(c->h_bout);
+        c->h_bout = nullptr;
+        c->h_bout_bytes = 0;
+        HIP_TRY(hipHostMalloc((void**)&c->h_bout, total, hipHostMallocDefault));
+        c->h_bout_bytes = total;
+    }
+    int32_t* h_counts = (int32_t*)(c->h_bout + rec_bytes);
+    for (int f = 0; f < n_frames; ++f) h_counts[2 * f] = -1, h_counts[2 * f + 1] = 0;
+    if (c->profiling && !c->profiling_keep) c->clear_timings();
+    if (int e = prepare_templates(c, c->stream, threshold, cap)) return e;
+    if (mask) HIP_TRY(hipMemcpyAsync(c->d_mask[0].p, mask, (size_t)rows * cols, hipMemcpyHostToDevice, c->stream));
+    sbm_match_rec* const user_mo = c->mirror_out;
+    int32_t* const user_mc = c->mirror_count;
+    int rc = 0;
+    for (int f0 = 0, k = 0; f0 < n_frames && !rc; f0 += sub, ++k) {
+        const int nf = std::min(sub, n_frames - f0), buf = k & 1;
+        // the kernels of sub-batch k-2 must have finished reading this input buffer
+        if (k >= 2 && hipStreamWaitEvent(c->copy_stream, c->ev_free[buf], 0) != hipSuccess) rc = fail(SBM_ERR_HIP, "stream wait failed");
+        for (int f = 0; f < nf && !rc; ++f) {
+            uint8_t* dst = c->d_in[buf].as<uint8_t>() + (size_t)f * frame_bytes;
+            // one DMA per frame when the caller's memory is pinned (sbm_pin_host_buffer / hipHostMalloc); staged by the
+            // runtime otherwise -- either way the kernels of the previous sub-batch keep the GPU busy meanwhile
+            hipError_t he = stride == cols * channels
+                                ? hipMemcpyAsync(dst, frames[f0 + f], frame_bytes, hipMemcpyHostToDevice, c->copy_stream)
+                                : hipMemcpy2DAsync(dst, (size_t)cols * channels, frames[f0 + f], stride, (size_t)cols * channels, rows,
+                                                   hipMemcpyHostToDevice, c->copy_stream);
+            if (he != hipSuccess) rc = fail(SBM_ERR_HIP, "frame upload failed: %s", hipGetErrorString(he));
+        }
+        if (rc) break;
+        if (hipEventRecord(c->ev_up[buf], c->copy_stream) != hipSuccess || hipStreamWaitEvent(c->stream, c->ev_up[buf], 0) != hipSuccess) {
+            rc = fail(SBM_ERR_HIP, "event record / wait failed");
+            break;
+        }
+        sbm_match_rec* d_out = c->d_bout.as<sbm_match_rec>() + (size_t)f0 * cap;
+        int32_t* d_cnt = (int32_t*)((char*)c->d_bout.p + rec_bytes) + 2 * f0;
+        c->mirror_out = (sbm_match_rec*)c->h_bout + (size_t)f0 * cap;
+        c->mirror_count = h_counts + 2 * f0;
+        rc = enqueue_pyramid(c, c->stream, c->d_in[buf].as<uint8_t>(), cols * channels, mask ? c->d_mask[0].as<uint8_t>() : nullptr, d_cnt, nf,
+                             (int64_t)frame_bytes);
+        if (!rc) rc = enqueue_coarse(c, c->stream, d_out, cap, d_cnt, nf);
+        if (!rc) rc = enqueue_local(c, c->stream, d_out, cap, d_cnt, nf);
+        if (!rc && hipEventRecord(c->ev_free[buf], c->stream) != hipSuccess) rc = fail(SBM_ERR_HIP, "event record failed");
+    }
+    c->mirror_out = user_mo;
+    c->mirror_count = user_mc;
+    if (rc) {
+        (void)hipDeviceSynchronize();
+        return rc;
+    }
+    c->pending.active = true;
+    c->pending.n_frames = n_frames;
+    c->pending.cap = cap;
+    return 0;
+}
+
+int sbm_match_batch_host_end(sbm_ctx* c, sbm_match_rec* out, int32_t* counts)
+{
+    if (!c || !out || !counts) return fail(SBM_ERR_INVALID, "null argument");
+    if (!c->pending.active) return fail(SBM_ERR_STATE, "no host batch in flight");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    c->pending.active = false;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int n = c->pending.n_frames;
+    const int64_t cap = c->pending.cap;
+    const int32_t* h_counts = (const int32_t*)(c->h_bout + (size_t)n * (size_t)cap * sizeof(sbm_match_rec));
+    int bad = -1;
+    for (int f = 0; f < n; ++f) {
+        counts[2 * f] = h_counts[2 * f];
+        counts[2 * f + 1] = h_counts[2 * f + 1];
+        const int64_t k = std::min<int64_t>(std::max(h_counts[2 * f], 0), cap);
+        if (k > 0) memcpy(out + (size_t)f * cap, (const sbm_match_rec*)c->h_bout + (size_t)f * cap, (size_t)k * sizeof(sbm_match_rec));
+        if ((h_counts[2 * f] < 0 || h_counts[2 * f] > cap || h_counts[2 * f + 1]) && bad < 0) bad = f;
+    }
+    if (c->profiling) collect_timings(c);
+    if (bad >= 0)
+        return fail(SBM_ERR_CAPACITY, "frame %d: %d matches (overflow flag %d) exceed the per-frame capacity %lld", bad, h_counts[2 * bad],
+                    h_counts[2 * bad + 1], (long long)cap);
+    return 0;
+}
+
+int sbm_match_batch_host(sbm_ctx* c, const uint8_t* const* frames, int32_t n_frames, int32_t rows, int32_t cols, int32_t stride,
+                         int32_t channels, const uint8_t* mask, float threshold, sbm_match_rec* out, int64_t cap, int32_t* counts,
+                         int32_t sub_batch)
+{
+    if (!out || !counts) return fail(SBM_ERR_INVALID, "null argument");
+    if (int e = sbm_match_batch_host_begin(c, frames, n_frames, rows, cols, stride, channels, mask, threshold, cap, sub_batch)) return e;
+    return sbm_match_batch_host_end(c, out, counts);
+}
+
+int sbm_pin_host_buffer(sbm_ctx* c, const void* p, int64_t bytes)
+{
+    if (!c || !p || bytes <= 0) return fail(SBM_ERR_INVALID, "bad buffer");
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    for (auto& pr : c->pinned)
+        if (pr.p == (const uint8_t*)p) return fail(SBM_ERR_STATE, "buffer %p is already pinned by this context (unpin it first)", p);
+    hipError_t e = hipHostRegister((void*)p, (size_t)bytes, hipHostRegisterPortable); // every device of the process may DMA from it
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(SBM_ERR_HIP, "hipHostRegister(%p, %lld) failed: %s", p, (long long)bytes, hipGetErrorString(e));
+    }
+    c->pinned.push_back({(const uint8_t*)p, (size_t)bytes});
+    return 0;
+}
+
+int sbm_unpin_host_buffer(sbm_ctx* c, const void* p)
+{
+    if (!c || !p) return fail(SBM_ERR_INVALID, "bad buffer");
+    for (size_t i = 0; i < c->pinned.size(); ++i)
+        if (c->pinned[i].p == (const uint8_t*)p) {
+            HIP_TRY(hipSetDevice(c->cfg.device_id));
+            HIP_TRY(hipStreamSynchronize(c->stream)); // an upload from it may still be in flight
+            hipError_t e = hipHostUnregister((void*)p);
+            c->pinned.erase(c->pinned.begin() + i);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(SBM_ERR_HIP, "hipHostUnregister(%p) failed: %s", p, hipGetErrorString(e));
+            }
+            return 0;
+        }
+    return fail(SBM_ERR_STATE, "buffer %p was not pinned by this context", p);
 }
 
 int sbm_match(sbm_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t channels,
@@ -1993,6 +2199,50 @@ extern "C" int sbm_match_batch_device_banded(sbm_ctx* c, const void* d_imgs, int
         hipLaunchKernelGGL(k_copy_bytes, dim3((unsigned)std::min<size_t>((total / 16 + 255) / 256 + 1, 1024)), dim3(256), 0, s,
                            (const uint8_t*)result, (uint8_t*)gathered_mirror, total);
         HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+// Single-process multi-GPU match (sbm_match_sharded(ctxs[], n_gpus, ...)): the analogue of the reference's
+// OpenMP team (line2Dup.cpp:1166-1170) with one host thread and one context per GPU.  Every context holds the same
+// templates and its own selection (sbm_partition_templates + sbm_select_range / sbm_select_templates); the frame goes to
+// every GPU, each matches its template shard, the lists are concatenated on the host (the reduction of :1168).
+extern "C" int sbm_match_sharded(sbm_ctx* const* ctxs, int32_t n_ctx, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride,
+                                 int32_t channels, const uint8_t* mask, float threshold, sbm_match_rec* out, int64_t cap, int64_t* n_out)
+{
+    if (!ctxs || n_ctx < 1 || !n_out || (!out && cap > 0)) return fail(SBM_ERR_INVALID, "bad arguments");
+    for (int i = 0; i < n_ctx; ++i)
+        if (!ctxs[i]) return fail(SBM_ERR_INVALID, "context %d is null", i);
+    if (n_ctx == 1) return sbm_match(ctxs[0], img, rows, cols, stride, channels, mask, threshold, out, cap, n_out);
+    struct Shard {
+        std::vector<sbm_match_rec> recs;
+        int64_t n = 0;
+        int rc = 0;
+        std::string err;
+    };
+    std::vector<Shard> sh(n_ctx);
+    std::vector<std::thread> th;
+    for (int i = 0; i < n_ctx; ++i)
+        th.emplace_back([&, i]() {
+            Shard& me = sh[i];
+            me.recs.resize((size_t)std::max<int64_t>(cap, 1));
+            me.rc = sbm_match(ctxs[i], img, rows, cols, stride, channels, mask, threshold, me.recs.data(), (int64_t)me.recs.size(), &me.n);
+            if (me.rc) me.err = sbm_last_error(); // the message is thread-local: carry it to the caller's thread
+        });
+    for (auto& t : th) t.join();
+    int64_t total = 0;
+    for (int i = 0; i < n_ctx; ++i) {
+        if (sh[i].rc && sh[i].rc != SBM_ERR_CAPACITY) return fail(sh[i].rc, "shard %d: %s", i, sh[i].err.c_str());
+        total += sh[i].n;
+    }
+    *n_out = total;
+    for (int i = 0; i < n_ctx; ++i)
+        if (sh[i].rc == SBM_ERR_CAPACITY) return fail(SBM_ERR_CAPACITY, "shard %d: %s", i, sh[i].err.c_str());
+    if (total > cap) return fail(SBM_ERR_CAPACITY, "%lld matches exceed the output capacity %lld", (long long)total, (long long)cap);
+    int64_t k = 0;
+    for (int i = 0; i < n_ctx; ++i) {
+        if (sh[i].n > 0) memcpy(out + k, sh[i].recs.data(), (size_t)sh[i].n * sizeof(sbm_match_rec));
+        k += sh[i].n;
     }
     return 0;
 }

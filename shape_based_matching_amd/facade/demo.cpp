@@ -12,6 +12,10 @@
 //       test.cpp:noise_test (test.cpp:455-491): match, boxes from templ[0].width/height, NMSBoxes(boxes, scores, 0, 0.5f)
 //   demo latency <templ_fmt> <class_id> <image> <threshold> <num_features> <n> [pad]
 //       n timed calls of detector.match(img, threshold, ids) on one cv::Mat, as a test.cpp-style caller sees them
+//       also: the same call with the frame buffer pinned (Detector::pinBuffer) and matchBatch from pinned host frames
+//   demo batch <templ_fmt> <class_id> <image> <threshold> <num_features> <n_frames> <pad> <devices>
+//       MI355X extensions: matchBatch / matchAsync+wait over n_frames shifted copies of the image against per-frame match(),
+//       and match() with setDevices(<devices>, e.g. 0,0) against the single-context match()
 //   demo instance <config.yaml> <image> <threshold>
 //       Detector::getInstance(path) (line2Dup.cpp:1366-1393) + match over the classes the config lists
 #include <chrono>
@@ -19,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <vector>
 
 #include "../../include/line2Dup.h"
 #include "../../include/nms.hpp"
@@ -169,6 +174,107 @@ int main(int argc, char** argv)
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / n;
             printf("latency %.1f us per Detector::match, image %dx%dx%d, %d templates, %zu matches\n", us, img.rows, img.cols,
                    img.channels(), detector.numTemplates(), n_matches);
+            // the same call with the caller's frame buffer page-locked (explicit: Detector::pinBuffer)
+            detector.pinBuffer(img);
+            for (int i = 0; i < 10; ++i) n_matches = detector.match(img, threshold, ids).size();
+            const auto t1 = std::chrono::steady_clock::now();
+            for (int i = 0; i < n; ++i) n_matches = detector.match(img, threshold, ids).size();
+            const double us_pin = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count() / n;
+            printf("latency_pinned %.1f us per Detector::match, %zu matches\n", us_pin, n_matches);
+            detector.unpinBuffer(img);
+            // the throughput path from host memory: 32 frames per matchBatch, uploads overlapped with the kernels; the frames
+            // live in one pinned block (a capture ring)
+            const int nb = 32;
+            Mat ring(img.rows * nb, img.cols, img.type());
+            std::vector<Mat> frames;
+            for (int b = 0; b < nb; ++b) {
+                Mat f = ring(Rect(0, b * img.rows, img.cols, img.rows));
+                img.copyTo(f);
+                frames.push_back(f);
+            }
+            detector.pinBuffer(ring);
+            size_t total = 0;
+            for (int i = 0; i < 3; ++i) detector.matchBatch(frames, threshold, ids);
+            const int reps = std::max(1, n / nb);
+            const auto t2 = std::chrono::steady_clock::now();
+            for (int i = 0; i < reps; ++i) {
+                total = 0;
+                for (const auto& l : detector.matchBatch(frames, threshold, ids)) total += l.size();
+            }
+            const double us_b = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t2).count() / (reps * nb);
+            printf("batch_pinned %.1f us per frame (matchBatch of %d frames from pinned host memory), %zu matches per batch, PCIe bound %.1f us at 48 GB/s\n",
+                   us_b, nb, total, (double)img.rows * img.cols * img.channels() / 48e3);
+            detector.unpinBuffer(ring);
+            return 0;
+        }
+        if (mode == "batch") {
+            if (argc < 10) return usage();
+            const std::string fmt = argv[2], class_id = argv[3], path = argv[4];
+            const float threshold = (float)atof(argv[5]);
+            const int num_features = atoi(argv[6]), nf = atoi(argv[7]), pad = atoi(argv[8]);
+            std::vector<int> devices;
+            for (const char* p = argv[9]; *p;) {
+                devices.push_back(atoi(p));
+                while (*p && *p != ',') ++p;
+                if (*p == ',') ++p;
+            }
+            line2Dup::Detector detector(num_features, {4, 8});
+            std::vector<std::string> ids{class_id};
+            detector.readClasses(ids, fmt);
+            Mat test_img = imread(path, IMREAD_UNCHANGED);
+            if (test_img.empty()) { fprintf(stderr, "cannot read %s\n", path.c_str()); return 1; }
+            Mat padded(test_img.rows + 2 * pad, test_img.cols + 2 * pad, test_img.type(), Scalar::all(0));
+            test_img.copyTo(padded(Rect(pad, pad, test_img.cols, test_img.rows)));
+            Mat img = padded(Rect(0, 0, 16 * (padded.cols / 16), 16 * (padded.rows / 16))).clone();
+            // frame b = the image shifted 8 b columns to the right (wrapping)
+            std::vector<Mat> frames;
+            const int esz = img.channels();
+            for (int b = 0; b < nf; ++b) {
+                Mat f(img.rows, img.cols, img.type());
+                const int sh = (8 * b) % img.cols;
+                for (int y = 0; y < img.rows; ++y) {
+                    memcpy(f.ptr(y) + (size_t)sh * esz, img.ptr(y), (size_t)(img.cols - sh) * esz);
+                    memcpy(f.ptr(y), img.ptr(y) + (size_t)(img.cols - sh) * esz, (size_t)sh * esz);
+                }
+                frames.push_back(f);
+            }
+            auto same = [](const std::vector<line2Dup::Match>& a, const std::vector<line2Dup::Match>& b) {
+                if (a.size() != b.size()) return false;
+                for (size_t i = 0; i < a.size(); ++i)
+                    if (!(a[i] == b[i]) || a[i].template_id != b[i].template_id) return false;
+                return true;
+            };
+            std::vector<std::vector<line2Dup::Match>> single;
+            for (const Mat& f : frames) single.push_back(detector.match(f, threshold, ids));
+            const auto batch = detector.matchBatch(frames, threshold, ids);
+            detector.matchAsync(frames, threshold, ids);
+            const auto async = detector.wait();
+            int ok_batch = batch.size() == single.size(), ok_async = async.size() == single.size();
+            size_t total = 0;
+            for (size_t f = 0; f < single.size(); ++f) {
+                ok_batch = ok_batch && same(batch[f], single[f]);
+                ok_async = ok_async && same(async[f], single[f]);
+                total += single[f].size();
+            }
+            // several contexts in one process: match() shards the templates, matchBatch() deals the frames
+            line2Dup::Detector multi(num_features, {4, 8});
+            multi.readClasses(ids, fmt);
+            multi.setDevices(devices);
+            int ok_dev = 1, ok_dev_batch = 1;
+            for (size_t f = 0; f < frames.size(); ++f) ok_dev = ok_dev && same(multi.match(frames[f], threshold, ids), single[f]);
+            const auto mb = multi.matchBatch(frames, threshold, ids);
+            for (size_t f = 0; f < frames.size(); ++f) ok_dev_batch = ok_dev_batch && mb.size() == frames.size() && same(mb[f], single[f]);
+            // unknown class: empty lists, as match() (:1136-1138)
+            const auto none = detector.matchBatch(frames, threshold, {std::string("no_such_class")});
+            int ok_none = none.size() == frames.size();
+            for (const auto& l : none) ok_none = ok_none && l.empty();
+            printf("batch frames %d matches %zu batch_same %d async_same %d devices %zu devices_same %d devices_batch_same %d unknown_class_empty %d\n", nf,
+                   total, ok_batch, ok_async, devices.size(), ok_dev, ok_dev_batch, ok_none);
+            for (const auto& m : single[0]) {
+                uint32_t bits;
+                memcpy(&bits, &m.similarity, 4);
+                printf("%d %d %u %s %d\n", m.x, m.y, bits, m.class_id.c_str(), m.template_id);
+            }
             return 0;
         }
         if (mode == "instance") {

@@ -13,6 +13,7 @@
 #include <iostream>
 #include <mutex>
 #include <stdexcept>
+#include <thread>
 
 using namespace cv;
 
@@ -301,7 +302,7 @@ Detector::Detector(int num_features, std::vector<int> T, float weak_thresh, floa
 }
 Detector::Detector(const Detector& o)
     : modality(makePtr<ColorGradient>(*o.modality)), pyramid_levels(o.pyramid_levels), T_at_level(o.T_at_level),
-      class_templates(o.class_templates), ctx_(nullptr), templates_dirty_(true), device_id_(o.device_id_)
+      class_templates(o.class_templates), ctx_(nullptr), templates_dirty_(true), device_id_(o.device_id_), device_ids_(o.device_ids_)
 {
 }
 Detector& Detector::operator=(const Detector& o)
@@ -313,6 +314,7 @@ Detector& Detector::operator=(const Detector& o)
         T_at_level = o.T_at_level;
         class_templates = o.class_templates;
         device_id_ = o.device_id_;
+        device_ids_ = o.device_ids_;
     }
     return *this;
 }
@@ -321,29 +323,46 @@ Detector::~Detector() { dropContext(); }
 void Detector::dropContext()
 {
     selection_valid_ = false;
-    if (ctx_) sbm_destroy(ctx_);
+    async_.active = false;
+    for (sbm_ctx* c : ctxs_) sbm_destroy(c);
+    ctxs_.clear();
     ctx_ = nullptr;
     templates_dirty_ = true;
 }
 
 void Detector::setDevice(int device_id)
 {
-    if (device_id != device_id_) dropContext();
+    if (device_id != device_id_ || device_ids_.size() > 1) dropContext();
     device_id_ = device_id;
+    device_ids_.clear();
+}
+
+void Detector::setDevices(const std::vector<int>& device_ids)
+{
+    CV_Assert(!device_ids.empty());
+    dropContext();
+    device_ids_ = device_ids;
+    device_id_ = device_ids[0];
 }
 
 void Detector::ensureContext() const
 {
     if (ctx_) return;
     CV_Assert(pyramid_levels >= 1 && pyramid_levels <= SBM_MAX_LEVELS && (int)T_at_level.size() >= pyramid_levels);
-    sbm_config cfg;
-    memset(&cfg, 0, sizeof cfg);
-    cfg.n_levels = pyramid_levels;
-    for (int l = 0; l < pyramid_levels; ++l) cfg.T[l] = T_at_level[l];
-    cfg.weak_threshold = modality->weak_threshold;
-    cfg.device_id = device_id_;
-    cfg.max_candidates = 0;
-    check(sbm_create(&cfg, &ctx_), "sbm_create");
+    const std::vector<int> devs = device_ids_.empty() ? std::vector<int>{device_id_} : device_ids_;
+    for (int d : devs) {
+        sbm_config cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.n_levels = pyramid_levels;
+        for (int l = 0; l < pyramid_levels; ++l) cfg.T[l] = T_at_level[l];
+        cfg.weak_threshold = modality->weak_threshold;
+        cfg.device_id = d;
+        cfg.max_candidates = 0;
+        sbm_ctx* c = nullptr;
+        check(sbm_create(&cfg, &c), "sbm_create");
+        ctxs_.push_back(c);
+    }
+    ctx_ = ctxs_[0];
     templates_dirty_ = true;
 }
 
@@ -378,33 +397,79 @@ void Detector::uploadTemplates() const
             tid.push_back((int32_t)t);
         }
     }
-    check(sbm_upload_templates(ctx_, (int32_t)cls.size(), levels.data(), feats.data(), (int64_t)feats.size(), cls.data(), tid.data()),
-          "sbm_upload_templates");
+    for (sbm_ctx* c : ctxs_)
+        check(sbm_upload_templates(c, (int32_t)cls.size(), levels.data(), feats.data(), (int64_t)feats.size(), cls.data(), tid.data()),
+              "sbm_upload_templates");
+    uploaded_class_of_ = cls;
     templates_dirty_ = false;
 }
 
-std::vector<Match> Detector::match(Mat source, float threshold, const std::vector<std::string>& class_ids, const Mat mask) const
+// Context, templates and class selection for a call.  sharded: the selected templates are divided over the contexts
+// (match() with several devices); else every context holds the whole selection (one device, or matchBatch, which deals
+// frames).  The engine's selection calls synchronise the device, so they are issued only when something changed.
+bool Detector::prepare(const std::vector<std::string>& class_ids, int rows, int cols, bool sharded) const
 {
-    std::vector<Match> matches;
-    CV_Assert(mask.empty() || mask.size() == source.size()); // :1086
-    CV_Assert(!source.empty() && source.depth() == CV_8U && (source.channels() == 1 || source.channels() == 3));
     ensureContext();
     if (templates_dirty_) uploadTemplates();
-    if (class_templates.empty()) return matches;
-
+    if (class_templates.empty()) return false;
     std::vector<int32_t> sel;
     if (!class_ids.empty()) { // unknown ids are skipped silently (:1136-1138)
         for (const std::string& id : class_ids) {
             auto it = std::find(uploaded_class_order_.begin(), uploaded_class_order_.end(), id);
             if (it != uploaded_class_order_.end()) sel.push_back((int32_t)(it - uploaded_class_order_.begin()));
         }
-        if (sel.empty()) return matches;
+        if (sel.empty()) return false;
     }
-    if (!selection_valid_ || sel != selected_) { // the selection call synchronises the device: only when it changes
-        check(sbm_select_classes(ctx_, sel.empty() ? nullptr : sel.data(), (int32_t)sel.size()), "sbm_select_classes");
-        selected_ = sel;
-        selection_valid_ = true;
+    const int mode = sharded && ctxs_.size() > 1 ? 1 : 0;
+    if (selection_valid_ && sel == selected_ && mode == selection_mode_ && (mode == 0 || (rows == selection_rows_ && cols == selection_cols_)))
+        return true;
+    if (mode == 0) {
+        for (sbm_ctx* c : ctxs_)
+            check(sbm_select_classes(c, sel.empty() ? nullptr : sel.data(), (int32_t)sel.size()), "sbm_select_classes");
+    } else {
+        // the list matchClass would walk (class_ids order, then template order, :1134-1139), cut into work-balanced pieces
+        std::vector<int32_t> act;
+        if (sel.empty()) {
+            act.resize(uploaded_class_of_.size());
+            for (size_t t = 0; t < act.size(); ++t) act[t] = (int32_t)t;
+        } else {
+            for (int32_t ci : sel)
+                for (size_t t = 0; t < uploaded_class_of_.size(); ++t)
+                    if (uploaded_class_of_[t] == ci) act.push_back((int32_t)t);
+        }
+        const int D = (int)ctxs_.size();
+        std::vector<int32_t> first(D), count(D);
+        check(sbm_partition_templates(ctx_, rows, cols, act.data(), (int32_t)act.size(), D, first.data(), count.data()), "sbm_partition_templates");
+        for (int d = 0; d < D; ++d) check(sbm_select_templates(ctxs_[d], act.data() + first[d], count[d]), "sbm_select_templates");
     }
+    selected_ = sel;
+    selection_mode_ = mode;
+    selection_rows_ = rows;
+    selection_cols_ = cols;
+    selection_valid_ = true;
+    return true;
+}
+
+// epilogue (:1142-1145): canonical sort, exact-duplicate removal, then the reference's own adjacent std::unique (its
+// operator== ignores template_id)
+std::vector<Match> Detector::toMatches(const void* recs_in, int64_t n) const
+{
+    std::vector<sbm_match_rec> recs((const sbm_match_rec*)recs_in, (const sbm_match_rec*)recs_in + n);
+    n = sbm_canonicalize(recs.data(), n);
+    std::vector<Match> matches;
+    matches.reserve((size_t)n);
+    for (int64_t i = 0; i < n; ++i)
+        matches.push_back(Match(recs[i].x, recs[i].y, recs[i].similarity, uploaded_class_order_[recs[i].class_idx], recs[i].template_id));
+    matches.erase(std::unique(matches.begin(), matches.end()), matches.end());
+    return matches;
+}
+
+std::vector<Match> Detector::match(Mat source, float threshold, const std::vector<std::string>& class_ids, const Mat mask) const
+{
+    CV_Assert(mask.empty() || mask.size() == source.size()); // :1086
+    CV_Assert(!source.empty() && source.depth() == CV_8U && (source.channels() == 1 || source.channels() == 3));
+    CV_Assert(!async_.active);
+    if (!prepare(class_ids, source.rows, source.cols, true)) return std::vector<Match>();
 
     Mat mask8;
     if (!mask.empty()) {
@@ -415,8 +480,13 @@ std::vector<Match> Detector::match(Mat source, float threshold, const std::vecto
     int64_t n = 0;
     for (;;) {
         const int64_t cap = (int64_t)(recs_.size() / sizeof(sbm_match_rec));
-        int rc = sbm_match(ctx_, source.data, source.rows, source.cols, (int)source.step, source.channels(),
-                           mask8.empty() ? nullptr : mask8.data, threshold, (sbm_match_rec*)recs_.data(), cap, &n);
+        // several devices: one host thread and context per device, each with its shard of the templates, lists
+        // concatenated (the OpenMP team of :1166-1170); one device: the plain call
+        int rc = ctxs_.size() > 1
+                     ? sbm_match_sharded(ctxs_.data(), (int32_t)ctxs_.size(), source.data, source.rows, source.cols, (int)source.step,
+                                         source.channels(), mask8.empty() ? nullptr : mask8.data, threshold, (sbm_match_rec*)recs_.data(), cap, &n)
+                     : sbm_match(ctx_, source.data, source.rows, source.cols, (int)source.step, source.channels(),
+                                 mask8.empty() ? nullptr : mask8.data, threshold, (sbm_match_rec*)recs_.data(), cap, &n);
         if (rc == SBM_ERR_CAPACITY && n > cap) {
             recs_.resize((size_t)n * sizeof(sbm_match_rec));
             continue;
@@ -424,15 +494,98 @@ std::vector<Match> Detector::match(Mat source, float threshold, const std::vecto
         check(rc, "sbm_match");
         break;
     }
-    // epilogue (:1142-1145): canonical sort, exact-duplicate removal, then the reference's own
-    // adjacent std::unique (its operator== ignores template_id)
-    sbm_match_rec* recs = (sbm_match_rec*)recs_.data();
-    n = sbm_canonicalize(recs, n);
-    matches.reserve((size_t)n);
-    for (int64_t i = 0; i < n; ++i)
-        matches.push_back(Match(recs[i].x, recs[i].y, recs[i].similarity, uploaded_class_order_[recs[i].class_idx], recs[i].template_id));
-    matches.erase(std::unique(matches.begin(), matches.end()), matches.end());
-    return matches;
+    return toMatches(recs_.data(), n);
+}
+
+// ---- throughput path: batches of frames from host memory, uploads overlapped with the kernels ----------------------
+void Detector::matchAsync(const std::vector<Mat>& sources, float threshold, const std::vector<std::string>& class_ids, const Mat mask) const
+{
+    CV_Assert(!async_.active && !sources.empty());
+    const Mat& s0 = sources[0];
+    for (const Mat& m : sources) {
+        CV_Assert(!m.empty() && m.depth() == CV_8U && (m.channels() == 1 || m.channels() == 3));
+        CV_Assert(m.rows == s0.rows && m.cols == s0.cols && m.channels() == s0.channels() && m.step == s0.step);
+    }
+    CV_Assert(mask.empty() || (mask.size() == s0.size() && mask.type() == CV_8UC1));
+    async_ = AsyncState();
+    async_.n_frames = sources.size();
+    if (!prepare(class_ids, s0.rows, s0.cols, false)) { // nothing selected: wait() returns empty lists
+        async_.active = true;
+        async_.cap = 0;
+        return;
+    }
+    Mat mask8;
+    if (!mask.empty()) mask8 = mask.isContinuous() ? mask : mask.clone();
+    // frames dealt over the devices in contiguous groups (frames are independent: Detector::match keeps no state)
+    const int D = (int)ctxs_.size(), n = (int)sources.size();
+    async_.cap = 1024;
+    for (int d = 0; d < D; ++d) {
+        async_.first.push_back((int)((int64_t)n * d / D));
+        async_.count.push_back((int)((int64_t)n * (d + 1) / D) - async_.first.back());
+    }
+    for (int d = 0; d < D; ++d) {
+        if (!async_.count[d]) continue;
+        std::vector<const uint8_t*> ptrs;
+        for (int f = 0; f < async_.count[d]; ++f) ptrs.push_back(sources[async_.first[d] + f].data);
+        const int rc = sbm_match_batch_host_begin(ctxs_[d], ptrs.data(), (int32_t)ptrs.size(), s0.rows, s0.cols, (int)s0.step, s0.channels(),
+                                                  mask8.empty() ? nullptr : mask8.data, threshold, async_.cap, 0);
+        if (rc) {
+            const std::string msg = sbm_last_error();
+            for (int e = 0; e < d; ++e) { // drain what was started
+                std::vector<sbm_match_rec> tmp((size_t)async_.count[e] * async_.cap);
+                std::vector<int32_t> cnt((size_t)async_.count[e] * 2);
+                if (async_.count[e]) (void)sbm_match_batch_host_end(ctxs_[e], tmp.data(), cnt.data());
+            }
+            CV_Error(rc == SBM_ERR_INVALID ? Error::StsBadArg : Error::StsError, "sbm_match_batch_host_begin: " + msg);
+        }
+    }
+    async_.active = true;
+}
+
+std::vector<std::vector<Match>> Detector::wait() const
+{
+    CV_Assert(async_.active);
+    async_.active = false;
+    std::vector<std::vector<Match>> out(async_.n_frames);
+    if (async_.cap == 0) return out;
+    int bad = 0;
+    std::string msg;
+    for (size_t d = 0; d < ctxs_.size(); ++d) {
+        const int nf = async_.count[d];
+        if (!nf) continue;
+        std::vector<sbm_match_rec> recs((size_t)nf * async_.cap);
+        std::vector<int32_t> cnt((size_t)nf * 2);
+        const int rc = sbm_match_batch_host_end(ctxs_[d], recs.data(), cnt.data());
+        if (rc && !bad) {
+            bad = rc;
+            msg = sbm_last_error();
+        }
+        if (rc) continue;
+        for (int f = 0; f < nf; ++f) out[async_.first[d] + f] = toMatches(recs.data() + (size_t)f * async_.cap, cnt[2 * f]);
+    }
+    if (bad) CV_Error(bad == SBM_ERR_INVALID ? Error::StsBadArg : Error::StsError, "sbm_match_batch_host_end: " + msg);
+    return out;
+}
+
+std::vector<std::vector<Match>> Detector::matchBatch(const std::vector<Mat>& sources, float threshold, const std::vector<std::string>& class_ids,
+                                                     const Mat mask) const
+{
+    if (sources.empty()) return std::vector<std::vector<Match>>();
+    matchAsync(sources, threshold, class_ids, mask);
+    return wait();
+}
+
+void Detector::pinBuffer(const Mat& frame) const
+{
+    CV_Assert(!frame.empty());
+    ensureContext();
+    check(sbm_pin_host_buffer(ctx_, frame.data, (int64_t)frame.step * frame.rows), "sbm_pin_host_buffer");
+}
+
+void Detector::unpinBuffer(const Mat& frame) const
+{
+    CV_Assert(!frame.empty() && ctx_);
+    check(sbm_unpin_host_buffer(ctx_, frame.data), "sbm_unpin_host_buffer");
 }
 
 int Detector::addTemplate(const Mat source, const std::string& class_id, const Mat& object_mask, float sscale, float orientation,

@@ -195,3 +195,40 @@ def test_facade_get_instance(tmp_path, case1):
     # a missing configuration file throws (line2Dup.cpp:1369-1373)
     r3 = subprocess.run([DEMO, "instance", str(tmp_path / "nope.yaml"), str(tmp_path / "frame.ppm"), "88"], capture_output=True, text=True)
     assert r3.returncode != 0
+
+
+def test_facade_batch_async_and_devices(tmp_path, oracle, case1):
+    """Round 3 extensions of the C++ Detector: matchBatch / matchAsync + wait (sub-batches of 8: 20 frames = 8 + 8 + 4, both
+    upload buffers re-used) and setDevices({0, 0, 0}) -- match() shards the templates over three contexts and host threads,
+    matchBatch() deals the frames over them -- each against per-frame match() in the demo, frame 0 against the oracle here"""
+    ts = case1["templates"].subset(range(280, 361, 2))
+    ts.class_ids = ["test"]
+    ts.template_id = np.arange(ts.n_templates, dtype=np.int32)
+    fmt = str(tmp_path / "%s_templ.yaml")
+    write_class_yaml(ts, fmt % "test")
+    img_path = str(tmp_path / "test.ppm")
+    write_ppm(img_path, case1["test"])
+    for nf, devs in ((20, "0,0,0"), (3, "0,0")):
+        r = subprocess.run([DEMO, "batch", fmt, "test", img_path, "88", "128", str(nf), "100", devs], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.strip().splitlines()
+        head = lines[0].split()
+        flags = dict(zip(head[1::2], head[2::2]))
+        assert flags["frames"] == str(nf) and int(flags["matches"]) > 0
+        for k in ("batch_same", "async_same", "devices_same", "devices_batch_same", "unknown_class_empty"):
+            assert flags[k] == "1", (k, lines[0])
+        got = [tuple(l.split()) for l in lines[1:]]
+        got = [(int(a), int(b), int(c), d, int(e)) for a, b, c, d, e in got]
+        img = case1["test"]
+        p = synth.embed(img, img.shape[0] + 200, img.shape[1] + 200, 100, 100)
+        frame = np.ascontiguousarray(p[: p.shape[0] // 16 * 16, : p.shape[1] // 16 * 16])
+        pyr = oracle.Pyramid.build(frame, [4, 8], 30.0)
+        want = oracle.canonicalize(pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 88.0))
+        pyr.free()
+        keep = []
+        for m in want:
+            k = (int(m["x"]), int(m["y"]), int(m["similarity"].view(np.uint32)), "test")
+            if keep and keep[-1][:4] == k:
+                continue
+            keep.append(k + (int(m["template_id"]),))
+        assert got == keep and len(got) > 0
