@@ -273,6 +273,14 @@ int sbm_match_templates_device(sbm_ctx* ctx, float threshold, void* d_out, int64
 int sbm_quantized_orientations(sbm_ctx* ctx, const uint8_t* img_host, int32_t rows, int32_t cols,
                                int32_t stride, int32_t channels, float weak_threshold,
                                float* magnitude, uint8_t* angle, float* angle_ori);
+/* The per-pixel scan of ColorGradientPyramid::extractTemplate (line2Dup.cpp:452-539; training side): the pixels of
+ * [2, rows-2) x [2, cols-2) that pass the 3x3-eroded mask (NULL: all), whose squared magnitude exceeds
+ * strong_threshold^2 and that the reference's row-major `magnitude_valid` scan accepts as 5x5 local maxima -- found
+ * by a data-parallel kernel (no strictly larger neighbour), ties among equal neighbours resolved in row-major order on
+ * the host exactly as the sequential scan does.  xy[i] = x | y << 16, in row-major order; *n_out = their number
+ * (SBM_ERR_CAPACITY if > cap).  The orientation test (:504) and the feature selection stay with the caller. */
+int sbm_extract_local_maxima(sbm_ctx* ctx, const float* magnitude_host, const uint8_t* mask_host, int32_t rows, int32_t cols,
+                             float strong_threshold, int32_t* xy, int64_t cap, int64_t* n_out);
 /* The 16-bin quantisation of hysteresisGradient (line2Dup.cpp:225: convertTo(CV_8U, 16/360) of the
  * phase image) as the match path computes it: an integer rule on the Sobel gradient (gx, gy), exact for
  * |gx|, |gy| <= 1020.  q16[i] in 0..16. */

@@ -58,6 +58,8 @@ def lib() -> C.CDLL:
         L.sbo_spread.argtypes = [vp, i32, i32, i32, vp]
         L.sbo_response_maps.argtypes = [vp, i64, vp]
         L.sbo_linearize.argtypes = [vp, i32, i32, i32, vp]
+        L.sbo_set_build_threads.argtypes = [i32]
+        L.sbo_set_build_threads.restype = None
         L.sbo_pyramid_build.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, f32]
         L.sbo_pyramid_build.restype = vp
         L.sbo_pyramid_from_quantized.argtypes = [vp, vp, vp, i32, vp]
@@ -282,6 +284,11 @@ def canonicalize(recs: np.ndarray) -> np.ndarray:
     recs = np.ascontiguousarray(recs, MATCH_DTYPE).copy()
     n = lib().sbo_canonicalize(_p(recs), len(recs))
     return recs[:n]
+
+
+def set_build_threads(n: int) -> None:
+    """threads of the pyramid build's row loops (1 = serial, the default); results do not depend on it"""
+    lib().sbo_set_build_threads(int(n))
 
 
 def match_set(recs: np.ndarray) -> set:

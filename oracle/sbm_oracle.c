@@ -35,10 +35,21 @@ static inline int reflect101(int p, int len)
 /* ------------------------------------------------------------------------- */
 static const int GK7[7] = {8, 28, 56, 72, 56, 28, 8};
 
+/* Threads of the pyramid build (sbo_set_build_threads; 1 = the plain serial restatement the parity tests use).  The
+ * reference's build is a chain of OpenCV calls (line2Dup.cpp:1084-1120) that OpenCV itself runs over row bands with
+ * parallel_for_; the bench's cpu_baseline leg sets this to the host's physical cores so that the CPU figure has the
+ * reference's shape (row-band parallel build + the OpenMP template loop of :1166-1170).  Every loop below that carries
+ * the pragma writes disjoint rows: results do not depend on the thread count. */
+static int g_build_threads = 1;
+void sbo_set_build_threads(int n) { g_build_threads = n < 1 ? 1 : n; }
+int sbo_get_build_threads(void) { return g_build_threads; }
+#define SBO_ROWS_PARALLEL _Pragma("omp parallel for schedule(static) num_threads(g_build_threads) if (g_build_threads > 1)")
+
 void sbo_gaussian7(const uint8_t* src, int rows, int cols, int ch, int stride, uint8_t* dst)
 {
     const int n = cols * ch;
     uint16_t* tmp = (uint16_t*)malloc((size_t)rows * n * sizeof(uint16_t));
+    SBO_ROWS_PARALLEL
     for (int r = 0; r < rows; ++r) {
         const uint8_t* s = src + (size_t)r * stride;
         uint16_t* t = tmp + (size_t)r * n;
@@ -49,6 +60,7 @@ void sbo_gaussian7(const uint8_t* src, int rows, int cols, int ch, int stride, u
                 t[c * ch + k] = (uint16_t)acc;
             }
     }
+    SBO_ROWS_PARALLEL
     for (int r = 0; r < rows; ++r) {
         uint8_t* d = dst + (size_t)r * n;
         for (int x = 0; x < n; ++x) {
@@ -65,6 +77,7 @@ void sbo_gaussian7(const uint8_t* src, int rows, int cols, int ch, int stride, u
 void sbo_sobel3(const uint8_t* sm, int rows, int cols, int ch, int16_t* dx, int16_t* dy)
 {
     const int n = cols * ch;
+    SBO_ROWS_PARALLEL
     for (int r = 0; r < rows; ++r) {
         const uint8_t* r0 = sm + (size_t)clampi(r - 1, 0, rows - 1) * n;
         const uint8_t* r1 = sm + (size_t)r * n;
@@ -122,6 +135,7 @@ void sbo_pyrdown(const uint8_t* src, int rows, int cols, int ch, int stride, uin
 {
     static const int K[5] = {1, 4, 6, 4, 1};
     const int dr = rows / 2, dc = cols / 2;
+    SBO_ROWS_PARALLEL
     for (int y = 0; y < dr; ++y)
         for (int x = 0; x < dc; ++x)
             for (int k = 0; k < ch; ++k) {
@@ -213,6 +227,7 @@ static void hysteresis(const float* magnitude, const float* angle_deg, int rows,
 {
     uint8_t* q = (uint8_t*)malloc((size_t)rows * cols);
     const float scale = (float)(16.0 / 360.0);
+    SBO_ROWS_PARALLEL
     for (size_t i = 0; i < (size_t)rows * cols; ++i) {
         /* convertTo(CV_8U, 16/360): saturate_cast<uchar>(cvRound(v * alpha)), round-half-even */
         long v = lrintf(angle_deg[i] * scale);
@@ -228,6 +243,7 @@ static void hysteresis(const float* magnitude, const float* angle_deg, int rows,
         for (int c = 1; c < cols - 1; ++c) q[(size_t)r * cols + c] &= 7;
 
     memset(out, 0, (size_t)rows * cols);
+    SBO_ROWS_PARALLEL
     for (int r = 1; r < rows - 1; ++r)
         for (int c = 1; c < cols - 1; ++c) {
             if (!(magnitude[(size_t)r * cols + c] > threshold)) continue;
@@ -258,6 +274,7 @@ void sbo_quantized_orientations(const uint8_t* src, int rows, int cols, int ch, 
     float* ang = angle_ori ? angle_ori : (float*)malloc(npx * sizeof(float));
     sbo_gaussian7(src, rows, cols, ch, stride, sm);
     sbo_sobel3(sm, rows, cols, ch, dx, dy);
+    SBO_ROWS_PARALLEL
     for (size_t i = 0; i < npx; ++i) {
         float fx, fy, m;
         if (ch == 1) {
@@ -296,13 +313,15 @@ void sbo_quantized_orientations(const uint8_t* src, int rows, int cols, int ch, 
 void sbo_spread(const uint8_t* src, int rows, int cols, int T, uint8_t* dst)
 {
     memset(dst, 0, (size_t)rows * cols);
-    for (int dr = 0; dr < T; ++dr)
-        for (int dc = 0; dc < T; ++dc)
-            for (int r = 0; r + dr < rows; ++r) {
+    SBO_ROWS_PARALLEL
+    for (int r = 0; r < rows; ++r) { /* a destination row is the OR of T source rows: rows are independent */
+        uint8_t* d = dst + (size_t)r * cols;
+        for (int dr = 0; dr < T && r + dr < rows; ++dr)
+            for (int dc = 0; dc < T; ++dc) {
                 const uint8_t* s = src + (size_t)(r + dr) * cols + dc;
-                uint8_t* d = dst + (size_t)r * cols;
                 for (int c = 0; c < cols - dc; ++c) d[c] |= s[c];
             }
+    }
 }
 
 /* computeResponseMaps.  line2Dup.cpp:637-747.  SIMILARITY_LUT (:632-635) in
@@ -310,6 +329,7 @@ void sbo_spread(const uint8_t* src, int rows, int cols, int T, uint8_t* dst)
  * else 0 (checked entry by entry against the table in tests/test_oracle_pins.py). */
 void sbo_response_maps(const uint8_t* spread, int64_t n, uint8_t* maps)
 {
+    SBO_ROWS_PARALLEL
     for (int o = 0; o < 8; ++o) {
         const unsigned self = 1u << o;
         const unsigned nb = (1u << ((o + 1) & 7)) | (1u << ((o + 7) & 7));
@@ -365,6 +385,7 @@ static int build_level(sbo_pyramid* p, int l, const uint8_t* q)
     uint8_t* maps = (uint8_t*)malloc(8 * n);
     sbo_spread(q, rows, cols, T, sp);
     sbo_response_maps(sp, (int64_t)n, maps);
+    SBO_ROWS_PARALLEL
     for (int o = 0; o < 8; ++o) sbo_linearize(maps + o * n, rows, cols, T, p->lm[l] + (size_t)o * p->lm_stride[l]);
     free(sp);
     free(maps);
@@ -597,7 +618,7 @@ int sbo_match_templates(const sbo_pyramid* p, const sbm_template_level* levels,
 #pragma omp parallel num_threads(n_threads)
     {
         uint16_t* sim = (uint16_t*)malloc(simn * sizeof(uint16_t));
-#pragma omp for schedule(dynamic, 1)
+#pragma omp for schedule(static)
         for (int t = 0; t < n_templates; ++t)
             match_one(p, levels + (size_t)t * L, feats, class_idx ? class_idx[t] : 0,
                       template_id ? template_id[t] : t, threshold, &per[t], sim);

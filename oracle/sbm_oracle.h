@@ -52,6 +52,9 @@ void sbo_linearize(const uint8_t* map, int rows, int cols, int T, uint8_t* lm /*
 
 /* ---- pyramid of flat linear memories ---- */
 typedef struct sbo_pyramid sbo_pyramid;
+/* threads of the pyramid build's row loops (default 1); results do not depend on it */
+void sbo_set_build_threads(int n);
+int sbo_get_build_threads(void);
 sbo_pyramid* sbo_pyramid_build(const uint8_t* img, int rows, int cols, int stride, int ch,
                                const uint8_t* mask, int n_levels, const int* T, float weak);
 sbo_pyramid* sbo_pyramid_from_quantized(const uint8_t* const* q, const int* rows, const int* cols,

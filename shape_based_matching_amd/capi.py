@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "sbm_comm_unique_id", "sbm_comm_init", "sbm_comm_destroy", "sbm_match_device_sharded", "sbm_match_batch_device_sharded",
     "sbm_match_batch_device_banded", "sbm_pin_host_buffer", "sbm_unpin_host_buffer",
     "sbm_select_templates", "sbm_partition_templates", "sbm_match_sharded",
-    "sbm_match_batch_host", "sbm_match_batch_host_begin", "sbm_match_batch_host_end",
+    "sbm_match_batch_host", "sbm_match_batch_host_begin", "sbm_match_batch_host_end", "sbm_extract_local_maxima",
 ]
 
 
@@ -54,6 +54,38 @@ class SbmError(RuntimeError):
 _lib = None
 
 
+def _one_hip_runtime_per_process() -> str:
+    """PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7) and link it
+    by the unversioned file name, so it is never matched to a system runtime that is already loaded: a process that loads
+    libsbm_hip.so (NEEDED libamdhip64.so.7 -> /opt/rocm) FIRST and imports torch LATER ends up with two HIP runtimes, and
+    the second one to initialise finds no device ("No HIP GPUs are available" from torch.cuda, round 2).  The other order
+    is fine: with torch's copy loaded first the loader resolves libsbm_hip's NEEDED entry to it by SONAME.  So, when a
+    torch with a bundled runtime is installed, make that order the only one: map torch's copy before libsbm_hip.so --
+    whether or not torch has been imported yet (it need not be, and is not imported here).  SBM_HIP_RUNTIME=system
+    keeps the system runtime (processes that never import torch)."""
+    if os.environ.get("SBM_HIP_RUNTIME", "") == "system":
+        return "system"
+    import importlib.util
+    import sys
+
+    t = sys.modules.get("torch")
+    if t is not None:
+        base = os.path.dirname(t.__file__)
+    else:
+        try:
+            spec = importlib.util.find_spec("torch")
+        except (ImportError, ValueError):
+            spec = None
+        if spec is None or not spec.submodule_search_locations:
+            return "system"
+        base = list(spec.submodule_search_locations)[0]
+    rt = os.path.join(base, "lib", "libamdhip64.so")
+    if not os.path.exists(rt):
+        return "system"
+    C.CDLL(rt, mode=C.RTLD_GLOBAL)
+    return rt
+
+
 def lib() -> C.CDLL:
     """Load libsbm_hip.so; raises if the HIP extension has not been built."""
     global _lib
@@ -64,6 +96,7 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} is missing: the HIP extension is not built (run __graft_entry__.build()); "
             "shape_based_matching_amd has no CPU fallback"
         )
+    _one_hip_runtime_per_process()
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     L.sbm_last_error.restype = C.c_char_p
@@ -107,6 +140,7 @@ def lib() -> C.CDLL:
     L.sbm_comm_destroy.argtypes = [vp]
     L.sbm_match_device_sharded.argtypes = [vp, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp, vp]
     L.sbm_match_batch_device_sharded.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp, vp]
+    L.sbm_extract_local_maxima.argtypes = [vp, vp, vp, i32, i32, f32, vp, i64, C.POINTER(i64)]
     L.sbm_select_templates.argtypes = [vp, vp, i32]
     L.sbm_partition_templates.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp]
     L.sbm_match_sharded.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, f32, vp, i64, C.POINTER(i64)]
@@ -266,6 +300,18 @@ class Context:
                                                    C.c_void_p(d_local), cap, C.c_void_p(d_gathered) if d_gathered else None,
                                                    C.c_void_p(gathered_mirror) if gathered_mirror else None, n_bands,
                                                    C.c_void_p(stream) if stream else None))
+
+    def extract_local_maxima(self, magnitude: np.ndarray, strong_threshold: float, mask: Optional[np.ndarray] = None) -> np.ndarray:
+        """[(x, y)] of the 5x5 local maxima extractTemplate accepts (row-major order)"""
+        mag = np.ascontiguousarray(magnitude, np.float32)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        cap = max(16, mag.size // 4)
+        xy = np.zeros(cap, np.int32)
+        n = C.c_int64(0)
+        _check(lib().sbm_extract_local_maxima(self._h, _p(mag), _p(m), mag.shape[0], mag.shape[1], C.c_float(strong_threshold), _p(xy), cap,
+                                              C.byref(n)))
+        xy = xy[: n.value]
+        return np.stack([xy & 0xFFFF, xy >> 16], axis=1)
 
     def select_templates(self, idx: Sequence[int]):
         a = np.ascontiguousarray(idx, np.int32)

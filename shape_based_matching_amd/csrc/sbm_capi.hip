@@ -19,6 +19,7 @@
 #include "../../include/sbm.h"
 #include "sbm_kernels.h"
 #include "sbm_quantize_stream.h"
+#include "sbm_train_kernels.h"
 
 using namespace sbm;
 
@@ -1749,6 +1750,72 @@ done:
     d_q.release();
     d_mag.release();
     d_ori.release();
+    return rc;
+}
+
+int sbm_extract_local_maxima(sbm_ctx* c, const float* magnitude, const uint8_t* mask, int32_t rows, int32_t cols, float strong_threshold,
+                             int32_t* xy, int64_t cap, int64_t* n_out)
+{
+    if (!c || !magnitude || !n_out || (!xy && cap > 0) || rows < 1 || cols < 1 || rows > 32767 || cols > 32767) return fail(SBM_ERR_INVALID, "bad argument");
+    *n_out = 0;
+    if (rows < 5 || cols < 5) return 0; // the scanned region [2, rows-2) x [2, cols-2) is empty
+    HIP_TRY(hipSetDevice(c->cfg.device_id));
+    const size_t npx = (size_t)rows * cols;
+    DevBuf d_mag, d_mask, d_xy, d_cnt;
+    std::vector<int32_t> pts;
+    int rc = 0;
+    int64_t dev_cap = std::max<int64_t>(4096, std::min<int64_t>((int64_t)npx / 8, 1 << 22));
+    if ((rc = d_mag.ensure(npx * 4)) || (mask && (rc = d_mask.ensure(npx))) || (rc = d_cnt.ensure(16))) goto done;
+    if (hipMemcpy(d_mag.p, magnitude, npx * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        (mask && hipMemcpy(d_mask.p, mask, npx, hipMemcpyHostToDevice) != hipSuccess)) {
+        rc = fail(SBM_ERR_HIP, "upload failed");
+        goto done;
+    }
+    for (;;) {
+        int32_t n = 0;
+        if ((rc = d_xy.ensure((size_t)dev_cap * 4))) goto done;
+        if (hipMemsetAsync(d_cnt.p, 0, 16, c->stream) != hipSuccess) {
+            rc = fail(SBM_ERR_HIP, "memset failed");
+            goto done;
+        }
+        hipLaunchKernelGGL(k_local_maxima5, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), 0, c->stream, d_mag.as<float>(),
+                           mask ? d_mask.as<uint8_t>() : nullptr, rows, cols, strong_threshold * strong_threshold, d_xy.as<int32_t>(),
+                           d_cnt.as<int32_t>(), (int)dev_cap);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&n, d_cnt.p, 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(SBM_ERR_HIP, "k_local_maxima5 failed: %s", hipGetErrorString(hipGetLastError()));
+            goto done;
+        }
+        if (n > dev_cap) { // more maxima than the buffer holds: once more with room for all of them
+            dev_cap = n;
+            continue;
+        }
+        pts.resize((size_t)n);
+        if (n && hipMemcpy(pts.data(), d_xy.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SBM_ERR_HIP, "download failed");
+        break;
+    }
+    if (!rc) {
+        // row-major order, then the reference's invalidation among equal-score neighbours: a maximum is dropped when an
+        // earlier kept one lies within its 5x5 window (sbm_train_kernels.h).  y << 16 | x sorts row-major as an integer.
+        std::sort(pts.begin(), pts.end());
+        std::vector<int32_t> kept;
+        size_t lo = 0; // first kept point that can still be within two rows of the current one
+        for (int32_t p : pts) {
+            const int y = p >> 16, x = p & 0xffff;
+            while (lo < kept.size() && (kept[lo] >> 16) < y - 2) ++lo;
+            bool ok = true;
+            for (size_t i = lo; i < kept.size() && ok; ++i) ok = std::abs((kept[i] & 0xffff) - x) > 2;
+            if (ok) kept.push_back(p);
+        }
+        *n_out = (int64_t)kept.size();
+        if ((int64_t)kept.size() > cap) rc = fail(SBM_ERR_CAPACITY, "%zu local maxima exceed the capacity %lld", kept.size(), (long long)cap);
+        else
+            for (size_t i = 0; i < kept.size(); ++i) xy[i] = kept[i];
+    }
+done:
+    d_mag.release();
+    d_mask.release();
+    d_xy.release();
+    d_cnt.release();
     return rc;
 }
 

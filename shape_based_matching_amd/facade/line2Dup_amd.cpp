@@ -205,64 +205,52 @@ bool ColorGradientPyramid::selectScatteredFeatures(const std::vector<Candidate>&
     return true;
 }
 
-// extractTemplate, line2Dup.cpp:452-539
+// extractTemplate (line2Dup.cpp:452-539).  The reference scans the image pixel by pixel on the host; here the scan is a
+// HIP kernel (csrc/sbm_train_kernels.h: every pixel above strong_threshold^2 that passes the eroded mask and has no
+// larger 5x5 neighbour, found in parallel; ties between equal neighbours resolved in row-major order as the reference's
+// `magnitude_valid` map does) and the host only turns the accepted maxima into candidates and spreads them out.
 bool ColorGradientPyramid::extractTemplate(Template& templ) const
 {
-    const int rows = magnitude.rows, cols = magnitude.cols;
-    Mat local_mask;
-    if (!mask.empty()) { // erode 3x3, BORDER_REPLICATE
-        local_mask.create(rows, cols, CV_8UC1);
-        for (int r = 0; r < rows; ++r)
-            for (int c = 0; c < cols; ++c) {
-                uchar m = 255;
-                for (int dr = -1; dr <= 1; ++dr)
-                    for (int dc = -1; dc <= 1; ++dc)
-                        m = std::min(m, mask.ptr(std::min(std::max(r + dr, 0), rows - 1))[std::min(std::max(c + dc, 0), cols - 1)]);
-                local_mask.ptr(r)[c] = m;
-            }
+    Mat mask8;
+    if (!mask.empty()) {
+        CV_Assert(mask.type() == CV_8UC1 && mask.size() == magnitude.size());
+        mask8 = mask.isContinuous() ? mask : mask.clone();
     }
+    Mat mag = magnitude.isContinuous() ? magnitude : magnitude.clone();
+    std::vector<int32_t> maxima((size_t)1 << 14);
+    int64_t n = 0;
+    for (;;) {
+        const int rc = sbm_extract_local_maxima(util_ctx(), mag.ptr<float>(), mask8.empty() ? nullptr : mask8.data, mag.rows, mag.cols,
+                                                strong_threshold, maxima.data(), (int64_t)maxima.size(), &n);
+        if (rc == SBM_ERR_CAPACITY && n > (int64_t)maxima.size()) {
+            maxima.resize((size_t)n);
+            continue;
+        }
+        check(rc, "sbm_extract_local_maxima");
+        break;
+    }
+    // accepted maxima arrive in row-major order; one with a quantised orientation is a feature candidate (:504)
     std::vector<Candidate> candidates;
-    const float threshold_sq = strong_threshold * strong_threshold;
-    Mat valid(rows, cols, CV_8UC1, Scalar(255));
-    for (int r = 2; r < rows - 2; ++r)
-        for (int c = 2; c < cols - 2; ++c) {
-            if (!local_mask.empty() && !local_mask.ptr(r)[c]) continue;
-            float score = 0;
-            if (valid.ptr(r)[c] > 0) { // 5x5 non-maximum suppression on the squared magnitude
-                score = magnitude.at<float>(r, c);
-                bool is_max = true;
-                for (int dr = -2; dr <= 2 && is_max; ++dr)
-                    for (int dc = -2; dc <= 2; ++dc) {
-                        if (dr == 0 && dc == 0) continue;
-                        if (score < magnitude.at<float>(r + dr, c + dc)) {
-                            score = 0;
-                            is_max = false;
-                            break;
-                        }
-                    }
-                if (is_max)
-                    for (int dr = -2; dr <= 2; ++dr)
-                        for (int dc = -2; dc <= 2; ++dc)
-                            if (dr != 0 || dc != 0) valid.ptr(r + dr)[c + dc] = 0;
-            }
-            const uchar a = angle.ptr(r)[c];
-            if (score > threshold_sq && a > 0) {
-                candidates.push_back(Candidate(c, r, label_of(a), score));
-                candidates.back().f.theta = angle_ori.at<float>(r, c);
-            }
-        }
-    if (candidates.size() < num_features) {
-        if (candidates.size() <= 4) {
-            std::cout << "too few features, abort" << std::endl;
-            return false;
-        }
-        std::cout << "have no enough features, exaustive mode" << std::endl;
+    candidates.reserve((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const int x = maxima[(size_t)i] & 0xffff, y = maxima[(size_t)i] >> 16;
+        const uchar a = angle.ptr(y)[x];
+        if (!a) continue;
+        candidates.push_back(Candidate(x, y, label_of(a), magnitude.at<float>(y, x)));
+        candidates.back().f.theta = angle_ori.at<float>(y, x);
     }
-    std::stable_sort(candidates.begin(), candidates.end());
-    const float distance = static_cast<float>(candidates.size() / num_features + 1);
+    if (candidates.size() <= 4 && candidates.size() < num_features) { // :507-512: five or more go on, however few
+        std::cout << "extractTemplate: only " << candidates.size() << " candidate features at pyramid level " << pyramid_level
+                  << ", giving up on this template" << std::endl;
+        return false;
+    }
+    if (candidates.size() < num_features)
+        std::cout << "extractTemplate: " << candidates.size() << " candidates for " << num_features << " features at pyramid level "
+                  << pyramid_level << ", taking what there is" << std::endl;
+    std::stable_sort(candidates.begin(), candidates.end()); // by score, ties stay in row-major order (:515)
+    const float distance = static_cast<float>(candidates.size() / num_features + 1); // integer division (:519)
     if (!selectScatteredFeatures(candidates, templ.features, num_features, distance)) return false;
-    templ.width = -1;
-    templ.height = -1;
+    templ.width = templ.height = -1; // set by cropTemplates
     templ.pyramid_level = pyramid_level;
     return true;
 }

@@ -31,20 +31,6 @@ def pytest_sessionstart(session):
         subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, check=False)
 
 
-@pytest.fixture(scope="session", autouse=True)
-def _torch_hip_first():
-    """On a GPU box initialise torch's HIP runtime before the first engine context: torch ships its own HIP runtime
-    library, and bringing it up after libsbm_hip's has already claimed the device failed in one test order."""
-    try:
-        import torch
-
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except Exception:
-        pass
-    yield
-
-
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O

@@ -533,3 +533,32 @@ def test_match_batch_device_banded_equals_whole_level_build(oracle, ctx_factory,
         with pytest.raises(capi.SbmError):  # 640 rows do not split into 3 bands
             ctx.match_batch_device_banded(d_imgs.data_ptr(), fs, B, rows, cols, cols * ch, ch, 85.0, d_local.data_ptr(), cap,
                                           d_gathered=d_gath.data_ptr() if with_comm else 0, n_bands=3, stream=stream.cuda_stream)
+
+
+def test_engine_context_before_torch_cuda_in_a_fresh_process():
+    """Round 2 finding: `RuntimeError: No HIP GPUs are available` from torch.cuda.Stream when an engine context was created
+    before torch initialised its (bundled, second) HIP runtime.  capi.lib() now maps torch's runtime first, so the process
+    has ONE HIP runtime whatever the order -- checked here in the failing order, in a fresh interpreter."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+from shape_based_matching_amd import capi
+ctx = capi.Context(T=(4, 8), weak_threshold=30.0, device_id=0)
+assert "torch" not in sys.modules
+import torch
+s = torch.cuda.Stream()
+x = torch.ones(1 << 16, device="cuda")
+torch.cuda.synchronize()
+assert float(x.sum()) == float(1 << 16)
+files = {{l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l}}
+assert len(files) == 1, files
+ctx.close()
+print("one runtime:", files)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -214,3 +214,61 @@ def test_resize_linear(oracle, ctx_factory):
                 continue
             got = ctx.resize_linear(img, fx, fy)
             assert got.shape == want.shape and np.array_equal(got, want), (shape, fx, fy)
+
+
+def _extract_scan_sequential(mag, thr, mask=None):
+    """ColorGradientPyramid::extractTemplate's scan (line2Dup.cpp:452-511) restated literally: row-major walk with the
+    magnitude_valid map; returns the pixels whose score survives and exceeds thr^2 (the orientation test is the caller's)"""
+    rows, cols = mag.shape
+    lm = None
+    if mask is not None:  # erode 3x3, BORDER_REPLICATE
+        p = np.pad(mask, 1, mode="edge")
+        lm = np.min([p[dr:dr + rows, dc:dc + cols] for dr in range(3) for dc in range(3)], axis=0)
+    valid = np.ones((rows, cols), bool)
+    out = []
+    for r in range(2, rows - 2):
+        for c in range(2, cols - 2):
+            if lm is not None and not lm[r, c]:
+                continue
+            score = 0.0
+            if valid[r, c]:
+                score = mag[r, c]
+                win = mag[r - 2:r + 3, c - 2:c + 3]
+                if (win > score).any():
+                    score = 0.0
+                else:
+                    valid[r - 2:r + 3, c - 2:c + 3] = False
+                    valid[r, c] = True
+            if score > thr * thr:
+                out.append((c, r))
+    return out
+
+
+def test_extract_local_maxima_kernel_equals_the_sequential_scan(ctx_factory, oracle, case1):
+    """Round 3: the training-side scan as a HIP kernel + row-major tie resolution.  Plateaus of equal squared magnitude
+    (chains where the second pixel is invalidated by the first and the third survives, blocks, diagonal runs, plateaus cut
+    by the mask), random integer fields with many ties, a real gradient magnitude image, images too small to scan."""
+    ctx = ctx_factory()
+    rs = np.random.RandomState(3)
+    cases = []
+    a = np.zeros((40, 64), np.float32)
+    a[10, 5:40] = 5000.0           # a horizontal plateau: every third pixel survives
+    a[20:30, 50] = 7000.0          # vertical
+    for k in range(12):            # diagonal
+        a[25 + k % 6, 8 + k] = 6000.0
+    a[32:36, 20:30] = 9000.0       # a block
+    cases.append((a, 60.0, None))
+    m = np.full((40, 64), 255, np.uint8)
+    m[:, 18:22] = 0                # the mask (eroded by one pixel) cuts the horizontal plateau
+    cases.append((a, 60.0, m))
+    cases.append((rs.randint(0, 6, (48, 80)).astype(np.float32) * 1000.0, 30.0, None))  # ties everywhere
+    cases.append((rs.randint(0, 3, (33, 47)).astype(np.float32) * 4000.0, 60.0, (rs.rand(33, 47) > 0.1).astype(np.uint8) * 255))
+    mag, _, _ = oracle.quantized_orientations(case1["train"], 30.0)
+    cases.append((np.ascontiguousarray(mag[:200, :260]), 60.0, None))
+    cases.append((np.ones((5, 5), np.float32) * 1e4, 10.0, None))   # exactly one scanned pixel
+    cases.append((np.ones((4, 9), np.float32) * 1e4, 10.0, None))   # nothing to scan
+    for mag, thr, mask in cases:
+        got = ctx.extract_local_maxima(mag, thr, mask)
+        want = _extract_scan_sequential(mag, thr, mask)
+        assert [tuple(p) for p in got.tolist()] == want, (mag.shape, thr)
+    assert len(_extract_scan_sequential(cases[0][0], 60.0)) > 10
