@@ -133,7 +133,10 @@ int sbm_pin_host_buffer(sbm_ctx* ctx, const void* host_ptr, int64_t bytes);
 int sbm_unpin_host_buffer(sbm_ctx* ctx, const void* host_ptr);
 
 /* Same path with the frame already resident in HBM.  Asynchronous: enqueues
- * every kernel on `stream` and returns.  Results go to caller-provided device
+ * every kernel on `stream` and returns.  The FIRST call after a change of state (templates, template selection,
+ * threshold, frame geometry, batch size) rebuilds small device tables on the context's own stream and synchronises
+ * the device before it enqueues anything: warm the context up with one call before capturing `stream` into a
+ * hipGraph or relying on asynchrony; steady-state calls never wait on the host and never touch another stream.  Results go to caller-provided device
  * buffers (d_out: cap records, d_count: one int32 — the number of matches,
  * which may exceed cap, in which case only cap records were stored) so the host
  * side can all-gather them over RCCL without another copy. */

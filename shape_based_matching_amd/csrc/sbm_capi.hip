@@ -99,6 +99,7 @@ static int coarse_mode_env()
 
 struct sbm_ctx {
     sbm_config cfg{};
+    int n_simd = 1024; // SIMDs of the device (4 per CU): 1024 on a whole MI355X, fewer on a partitioned one
     int L = 0;
     hipStream_t stream = nullptr;
     int64_t cand_cap = 0;
@@ -111,6 +112,8 @@ struct sbm_ctx {
     std::vector<int32_t> h_class, h_tid;
     std::vector<int32_t> h_active;
     DevBuf d_tls, d_fxy, d_flabel, d_flevel, d_foff, d_class, d_tid, d_active, d_rawmin, d_rawkeep;
+    DevBuf d_citems, d_cfoff; // coarse pass: one record + the first 64 feature offsets per active template (k_prep_coarse_items)
+    bool citems_dirty = true;
     DevBuf d_fxy_s, d_flabel_s, d_fcls; // refinement pass on the strip plane: features sorted by (x / T) & 15 per template level + 17 class offsets
     bool have_thr = false;
     float thr_cached = 0.f;
@@ -407,7 +410,7 @@ int quantize_stream_rows(const sbm_ctx* c, int rows, int cols, int ch, int frame
     // resident waves per SIMD the launch is sized for (experiment knob SBM_QS_WAVES, with SBM_QS_LDS capping the
     // workgroups per CU to match: fewer gradient waves leave registers for the other kernels' waves)
     static const int env_w = getenv("SBM_QS_WAVES") ? atoi(getenv("SBM_QS_WAVES")) : 0;
-    const int64_t slots = 1024 * (env_w > 0 ? env_w : (ch == 3 ? 3 : 6));
+    const int64_t slots = (int64_t)c->n_simd * (env_w > 0 ? env_w : (ch == 3 ? 3 : 6));
     // waves per row block: one per strip and frame, except that a narrow last strip is shared by several frames
     const int pack = qs_pack_lanes(rows, cols, ch, frames, img_fs, stride);
     const int64_t per_rb = pack ? (strips - 1) * frames + (frames + 64 / pack - 1) / (64 / pack) : strips * frames;
@@ -593,6 +596,7 @@ int ensure_thresholds(sbm_ctx* c, float thr, hipStream_t s)
     HIP_TRY(hipStreamSynchronize(s));
     c->thr_cached = thr;
     c->have_thr = true;
+    c->citems_dirty = true;
     return 0;
 }
 
@@ -605,12 +609,33 @@ int ensure_foff(sbm_ctx* c, hipStream_t s)
     const int blocks = (int)std::min<int64_t>((c->n_features + 255) / 256, 8192);
     SBM_LAUNCH(c, "k_prep_features", k_prep_features, dim3(blocks), dim3(256), 0, s, c->d_fxy.as<uint32_t>(),
                        c->d_flabel.as<uint8_t>(), c->d_flevel.as<uint8_t>(), c->n_features, g,
-                       g + SBM_MAX_LEVELS, g + 2 * SBM_MAX_LEVELS, st, c->d_foff.as<int32_t>());
+                       g + SBM_MAX_LEVELS, g + 2 * SBM_MAX_LEVELS, st, c->d_foff.as<int32_t>(), c->L - 1);
     HIP_TRY(hipGetLastError());
     // The similarity kernels may be enqueued on a different stream than `s` (graph replay, a caller's stream):
     // the table must be complete before any of them can start.  Only runs after a template / geometry change.
     HIP_TRY(hipStreamSynchronize(s));
     c->foff_dirty = false;
+    c->citems_dirty = true;
+    return 0;
+}
+
+// per-slot records of the coarse pass (template record + threshold + first feature offsets): after any change of the
+// active set, the thresholds, the templates or the geometry
+int ensure_citems(sbm_ctx* c, hipStream_t s)
+{
+    const int n_active = (int)c->h_active.size();
+    if (!c->citems_dirty || n_active == 0) return 0;
+    if (c->rows[c->L - 1] <= 0) return 0; // no geometry yet: the first match call comes back here
+    const int lc = c->L - 1, T = c->cfg.T[lc], W = c->cols[lc] / T, H = c->rows[lc] / T;
+    if (int e = c->d_citems.ensure((size_t)n_active * sizeof(CoarseItem))) return e;
+    if (int e = c->d_cfoff.ensure((size_t)n_active * 64 * 4)) return e;
+    const int zero_off = (int)(7 * c->lm_stride[lc] + (int64_t)T * T * W * H);
+    hipLaunchKernelGGL(k_prep_coarse_items, dim3((unsigned)std::min(n_active, 4096)), dim3(256), 0, s, c->d_active.as<int32_t>(), n_active,
+                       c->d_tls.as<DevTL>(), c->L, lc, c->d_rawmin.as<int32_t>(), c->d_foff.as<int32_t>(), T, W, H, zero_off,
+                       c->d_citems.as<CoarseItem>(), c->d_cfoff.as<int32_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s)); // consumers may run on another stream (as ensure_foff)
+    c->citems_dirty = false;
     return 0;
 }
 
@@ -741,12 +766,16 @@ int enqueue_pyramid(sbm_ctx* c, hipStream_t s, const uint8_t* d_img0, int stride
 
 // host-side preparation of the template loop: validation, integer thresholds, feature offsets.
 // May synchronise (only when something changed); never called inside a stream capture.
-int prepare_templates(sbm_ctx* c, hipStream_t s, float threshold, int64_t cap)
+// The tables are (re)built on the CONTEXT's stream and that stream is synchronised by the host, whatever stream the
+// consumers will run on: the caller's stream is neither waited on nor given work here (a host wait on
+// the caller's stream fails while that stream is being captured).  Nothing is enqueued when nothing changed.
+int prepare_templates(sbm_ctx* c, hipStream_t, float threshold, int64_t cap)
 {
     if (c->n_templates == 0) return fail(SBM_ERR_STATE, "no templates uploaded");
     if (cap < 0 || cap > INT32_MAX) return fail(SBM_ERR_INVALID, "bad output capacity");
-    if (int e = ensure_thresholds(c, threshold, s)) return e;
-    return ensure_foff(c, s);
+    if (int e = ensure_thresholds(c, threshold, c->stream)) return e;
+    if (int e = ensure_foff(c, c->stream)) return e;
+    return ensure_citems(c, c->stream);
 }
 
 // coarse pass over the active templates (reset + k_similarity_coarse; single-level pyramids emit here)
@@ -784,8 +813,8 @@ int enqueue_coarse(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap,
             if (per_wave)
                 SBM_LAUNCH(c, "k_similarity_coarse", k_similarity_coarse_wave, dim3(chunks, (cnt + 3) / 4, frames), dim3(256), 0, s,
                            c->d_lm[lc].as<uint8_t>(), c->lm_stride[lc], c->rows[lc], c->cols[lc], T, W, H, L, lc, c->d_tls.as<DevTL>(),
-                           c->d_fxy.as<uint32_t>(), c->d_foff.as<int32_t>(), c->d_active.as<int32_t>() + first, cnt,
-                           c->d_rawmin.as<int32_t>(), c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
+                           c->d_foff.as<int32_t>(), c->d_citems.as<CoarseItem>() + first, c->d_cfoff.as<int32_t>() + (size_t)first * 64, cnt,
+                           c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
                            c->d_cands.as<Cand>(), counters, (int)c->cand_cap, (int64_t)8 * c->lm_stride[lc]);
             else
                 SBM_LAUNCH(c, "k_similarity_coarse", k_similarity_coarse, dim3(chunks, cnt, frames), dim3(256), 0, s, c->d_lm[lc].as<uint8_t>(),
@@ -982,6 +1011,11 @@ int sbm_create(const sbm_config* cfg, sbm_ctx** out)
     sbm_ctx* c = new sbm_ctx();
     c->cfg = *cfg;
     c->L = cfg->n_levels;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_simd = 4 * prop.multiProcessorCount;
+        else (void)hipGetLastError();
+    }
     c->cand_cap = cfg->max_candidates > 0 ? cfg->max_candidates : (int64_t)1 << 20;
     if (c->cand_cap > INT32_MAX / 2) c->cand_cap = INT32_MAX / 2;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -1033,7 +1067,7 @@ void sbm_destroy(sbm_ctx* c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side) (void)hipStreamDestroy(c->side);
     c->clear_timings();
-    DevBuf* singles[] = {&c->d_tls, &c->d_fxy, &c->d_flabel, &c->d_flevel, &c->d_foff, &c->d_class, &c->d_tid, &c->d_active, &c->d_fxy_s, &c->d_flabel_s, &c->d_fcls,
+    DevBuf* singles[] = {&c->d_tls, &c->d_fxy, &c->d_flabel, &c->d_flevel, &c->d_foff, &c->d_class, &c->d_tid, &c->d_active, &c->d_citems, &c->d_cfoff, &c->d_fxy_s, &c->d_flabel_s, &c->d_fcls,
                          &c->d_rawmin, &c->d_rawkeep, &c->d_geo, &c->d_cands, &c->d_counters, &c->d_out, &c->d_outcount,
                          &c->d_scratch};
     for (DevBuf* b : singles) b->release();
@@ -1156,6 +1190,7 @@ static int set_active(sbm_ctx* c, std::vector<int32_t>& act)
     if (int e = c->d_active.ensure(std::max<size_t>(act.size(), 1) * 4)) return e;
     if (!act.empty()) HIP_TRY(hipMemcpy(c->d_active.p, act.data(), act.size() * 4, hipMemcpyHostToDevice));
     c->h_active.swap(act);
+    c->citems_dirty = true;
     c->drop_graphs(); // grid sizes depend on the active set
     return 0;
 }

@@ -1112,14 +1112,49 @@ __global__ __launch_bounds__(256) void k_prep_features(const uint32_t* __restric
                                                        const int* __restrict__ Tl, const int* __restrict__ Wl,
                                                        const int* __restrict__ Hl,
                                                        const int64_t* __restrict__ stride_l,
-                                                       int32_t* __restrict__ foff)
+                                                       int32_t* __restrict__ foff, int lc)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int l = flevel[i];
         const int T = Tl[l], W = Wl[l], H = Hl[l];
         const int x = fxy[i] & 0xffff, y = fxy[i] >> 16;
         int64_t off = (int64_t)flabel[i] * stride_l[l] + (int64_t)((y % T) * T + (x % T)) * W * H + (int64_t)(y / T) * W + x / T;
+        // Coarsest level: a feature outside the image is skipped by the reference (:836-837) -- it adds nothing.  Point it
+        // at the zero tail of the last orientation's plane (every position of the span reads 0 there), so that the coarse
+        // pass needs neither the feature's coordinates nor a bounds test.  The refinement levels keep the plain offset:
+        // there the test is on the feature moved by the candidate's patch origin.
+        if (l == lc && (x >= W * T || y >= H * T)) off = 7 * stride_l[l] + (int64_t)T * T * W * H;
         foff[i] = (int32_t)off;
+    }
+}
+
+// What one work item of the coarse pass needs about its template, in one 32-byte record (one scalar load instead of
+// the chain active[] -> tls[] -> raw_min[]), and the offsets of the template's first 64 coarsest-level features,
+// indexed by the item's slot (a vector load that does not wait for the record).
+struct CoarseItem {
+    int32_t t, feat_off, nf, npos, rmin, pad0, pad1, pad2;
+};
+__global__ __launch_bounds__(256) void k_prep_coarse_items(const int32_t* __restrict__ active, int n_active, const DevTL* __restrict__ tls,
+                                                           int L, int lc, const int32_t* __restrict__ raw_min,
+                                                           const int32_t* __restrict__ foff, int T, int W, int H, int zero_off,
+                                                           CoarseItem* __restrict__ items, int32_t* __restrict__ cfoff)
+{
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n_active * 64; idx += gridDim.x * 256) {
+        const int slot = idx >> 6, i = idx & 63;
+        const int t = active[slot];
+        const DevTL tl = tls[(size_t)t * L + lc];
+        cfoff[idx] = i < tl.nf ? foff[tl.feat_off + i] : zero_off;
+        if (i == 0) {
+            const int wf = (tl.width - 1) / T + 1, hf = (tl.height - 1) / T + 1;
+            CoarseItem it;
+            it.t = t;
+            it.feat_off = tl.feat_off;
+            it.nf = tl.nf;
+            it.npos = (H - hf) * W + (W - wf) + 1;
+            it.rmin = raw_min[(size_t)t * L + lc];
+            it.pad0 = it.pad1 = it.pad2 = 0;
+            items[slot] = it;
+        }
     }
 }
 
@@ -1320,9 +1355,11 @@ __device__ __forceinline__ uint32_t coarse_pk_max_u16(uint32_t a, uint32_t b) //
 // 4*done -- a weaker bound prunes little and rmin <= 2*nf never gets there) the wave looks whether any of its 1024
 // positions is still alive and returns false if none is.  Positions past the template's span may hold anything:
 // they can only keep the wave going, the caller's scan ignores them.  Returns true with the complete sums.
-__device__ __forceinline__ bool accumulate_features16_pruned(const uint8_t* __restrict__ lm, const uint32_t* __restrict__ fxy,
-                                                             const int32_t* __restrict__ foff, int nf, int rows, int cols,
-                                                             int j0, bool lane_on, int zero_off, int rmin,
+// foff: the template's coarsest-level feature offsets with the out-of-image test already folded in (k_prep_features:
+// such a feature points at the zero tail); sel0: the first 64 of them, loaded by the caller before it knew the template
+// record (k_prep_coarse_items: lanes past nf hold the zero tail's offset).
+__device__ __forceinline__ bool accumulate_features16_pruned(const uint8_t* __restrict__ lm, const int32_t* __restrict__ foff, int sel0,
+                                                             int nf, int j0, bool lane_on, int zero_off, int rmin,
                                                              uint32_t (&lo)[4], uint32_t (&hi)[4])
 {
     const int lane = threadIdx.x & 63;
@@ -1332,14 +1369,8 @@ __device__ __forceinline__ bool accumulate_features16_pruned(const uint8_t* __re
     nf = __builtin_amdgcn_readfirstlane(nf);
     rmin = __builtin_amdgcn_readfirstlane(rmin);
     for (int b = 0; b < nf; b += 64) {
-        int sel = zero_off;
-        if (b + lane < nf) {
-            // both loads issued together (a load of foff under the bounds test would wait for fxy first)
-            const uint32_t xy = fxy[b + lane];
-            const int off = foff[b + lane];
-            const int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
-            if (x < cols && y < rows) sel = off;
-        }
+        int sel = sel0;
+        if (b > 0) sel = b + lane < nf ? foff[b + lane] : zero_off;
         const int nb = nf - b < 64 ? nf - b : 64;
         auto batch = [&](auto N, int u) {
             constexpr int n = decltype(N)::value;
@@ -1567,24 +1598,27 @@ __global__ __launch_bounds__(256) void k_similarity_coarse(
 // single-frame latency low) only multiplies the per-item overhead.  Same arguments, same candidates.
 __global__ __launch_bounds__(256) void k_similarity_coarse_wave(
     const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int lc,
-    const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
-    const int32_t* __restrict__ active, int n_active, const int32_t* __restrict__ raw_min, const int32_t* __restrict__ raw_keep,
+    const DevTL* __restrict__ tls, const int32_t* __restrict__ foff, const CoarseItem* __restrict__ items,
+    const int32_t* __restrict__ cfoff, int n_active, const int32_t* __restrict__ raw_keep,
     const int32_t* __restrict__ class_idx, const int32_t* __restrict__ template_id, Cand* __restrict__ cands,
     int32_t* __restrict__ counters, int cap, int64_t lm_fs)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int chunk_id, slot4, frame;
     coarse_block_item(chunk_id, slot4, frame);
-    const int templ_slot = slot4 * 4 + wave;
+    const int templ_slot = __builtin_amdgcn_readfirstlane(slot4 * 4 + wave);
     if (templ_slot >= n_active) return;
+    // The item's dependent chain is two loads deep: {template record (scalar cache), its first 64 feature offsets
+    // (vector load)} -- both indexed by the slot -- then the linear memories.  (Round 2: active[] -> tls[] -> raw_min[]
+    // and fxy[] / foff[] -> linear memories: a third of the launch's time at threshold 100.)
+    const int sel0 = cfoff[(size_t)templ_slot * 64 + lane];
+    const CoarseItem it = items[templ_slot];
     lm += (size_t)frame * lm_fs;
     cands += (size_t)frame * cap;
     counters += (size_t)frame * 40;
-    // wave-uniform by construction: say so, and the template record and threshold come through the scalar cache
-    const int t = __builtin_amdgcn_readfirstlane(active[templ_slot]);
-    const DevTL tl = tls[(size_t)t * L + lc];
-    const int npos = template_positions(tl, W, H, T);
-    const int rmin = raw_min[(size_t)t * L + lc];
+    const int t = it.t;
+    const int npos = it.npos;
+    const int rmin = it.rmin;
     const int base = chunk_id * COARSE_POS_PER_BLOCK;
     const int total = W * H;
     if (base >= total) return;
@@ -1594,8 +1628,7 @@ __global__ __launch_bounds__(256) void k_similarity_coarse_wave(
     if (base < npos) {
         const int zero_off = (int)(7 * lm_stride + (int64_t)T * T * W * H);
         const bool lane_on = j0 < npos + 16;
-        if (!accumulate_features16_pruned(lm, fxy + tl.feat_off, foff + tl.feat_off, tl.nf, rows, cols, lane_on ? j0 : 0, lane_on,
-                                          zero_off, rmin, lo, hi))
+        if (!accumulate_features16_pruned(lm, foff + it.feat_off, sel0, it.nf, lane_on ? j0 : 0, lane_on, zero_off, rmin, lo, hi))
             return; // no position of this item can reach rmin
     }
     const int offset = T / 2 + (T % 2 - 1);

@@ -562,3 +562,43 @@ print("one runtime:", files)
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("thr", [0.0, -1.0, 10.0])
+def test_strip_plane_refinement_with_clamped_patches(oracle, ctx_factory, case1, thr):
+    """the strip-interleaved refinement path (level-0 grid width a multiple of 16, batched entry point)
+    with templates that do not fit the frame -- max_x / max_y below the border or negative, so every patch origin is
+    clamped (line2Dup.cpp:1227-1245) -- and with thresholds <= 0, where every coarse position is a candidate, the four
+    frame corners included."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    ts = case1["templates"].subset([0, 90, 340])  # 264 x 266 boxes at level 0
+    img = case1["test"]
+    frames = [np.ascontiguousarray(img[60:60 + 288, 40:40 + 512]),    # max_y = 288 - 264 - 32 < 0
+              np.ascontiguousarray(img[100:100 + 320, 0:320])]        # other frame below; both dimensions too small here
+    for fr in frames:
+        rows, cols = fr.shape[:2]
+        assert cols % 64 == 0 and rows % 16 == 0
+        B = 2
+        batch = np.stack([fr, np.ascontiguousarray(fr[::-1])])
+        ctx = ctx_factory(max_candidates=1 << 16)
+        ctx.upload_templates(ts)
+        cap, rec = 1 << 15, MATCH_DTYPE.itemsize
+        d_imgs = torch.from_numpy(batch).to(dev)
+        d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)
+        d_cnt = torch.zeros(B * 2, dtype=torch.int32, device=dev)
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        ctx.match_batch_device(d_imgs.data_ptr(), fr.size, B, rows, cols, cols * 3, 3, thr, d_out.data_ptr(), cap, d_cnt.data_ptr(),
+                               stream=stream.cuda_stream)
+        stream.synchronize()
+        cnt = d_cnt.cpu().numpy().reshape(B, 2)
+        out = d_out.cpu().numpy().reshape(B, cap * rec)
+        for f in range(B):
+            p = oracle.Pyramid.build(batch[f], [4, 8], 30.0)
+            want = p.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr)
+            p.free()
+            assert cnt[f, 1] == 0 and cnt[f, 0] == len(want), (f, cnt[f].tolist(), len(want))
+            assert key(out[f].view(MATCH_DTYPE)[: cnt[f, 0]]) == key(want)
+        assert len(want) >= 90  # thresholds <= 0 and 10: every coarse position of the (small) span is a candidate
