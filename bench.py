@@ -381,6 +381,9 @@ def main():
 
     slots = [Slot() for _ in range(max(1, args.inflight))]
     ctx = slots[0].ctx
+    if wl.stage == "match" and not os.environ.get("SBM_BENCH_LATENCY_SIZING"):
+        for sl in slots:  # the slots' batches are in flight together: size the launches for throughput
+            sl.ctx.set_pipeline_depth(len(slots))
     torch.cuda.synchronize()
     step_no = [0]
 
@@ -456,7 +459,13 @@ def main():
     elapsed = timed(args.warmup, args.steps)
 
     # one step at a time on one stream (latency-bound figure), same K steps, outside the timed region
-    single_ms = timed(0, args.steps, slots[0].run) / args.steps * 1e3 if len(slots) > 1 else elapsed / args.steps * 1e3
+    if len(slots) > 1:
+        slots[0].ctx.set_pipeline_depth(1)  # one batch in flight: latency sizing
+        single_ms = timed(2, args.steps, slots[0].run) / args.steps * 1e3
+        if wl.stage == "match" and not os.environ.get("SBM_BENCH_LATENCY_SIZING"):
+            slots[0].ctx.set_pipeline_depth(len(slots))
+    else:
+        single_ms = elapsed / args.steps * 1e3
 
     # every slot must hold the same, stable match list (checked outside the timed region)
     ref_counts = None
@@ -500,6 +509,10 @@ def main():
     # overlap on the GPU and stretch each other), timed with the dispatch packets' own start/stop timestamps
     # (hipExtLaunchKernelGGL events on the launch stream); kept out of the timed region above
     def kernel_pass(n):
+        # one batch at a time on one slot: size the launches for that (the hint is the number of batches in flight)
+        slots[0].ctx.set_pipeline_depth(1)
+        slots[0].run()
+        fence()
         slots[0].ctx.set_profiling(True, accumulate=True)
         per = {}
         for _ in range(n):
@@ -508,6 +521,8 @@ def main():
         for name, ms in slots[0].ctx.timings():
             per.setdefault(name, []).append(ms)
         slots[0].ctx.set_profiling(False)
+        if wl.stage == "match" and not os.environ.get("SBM_BENCH_LATENCY_SIZING"):
+            slots[0].ctx.set_pipeline_depth(len(slots))
         out = {}
         for name, v in per.items():
             launches = len(v) // n
@@ -549,6 +564,7 @@ def main():
             sl.ctx.set_profiling(False)
             return {k: np.asarray(v).reshape(n, -1).mean(axis=0) for k, v in per.items()}
 
+        sl.ctx.set_pipeline_depth(1)  # every figure below is one batch at a time
         base = kernel_us(sl.run)
         t1 = float(sum(v.sum() for v in base.values()))
         strong = {"one_gpu_kernels_us_per_step": t1, "assumed_xgmi_link_GBps": XGMI_LINK_GBS, "assumed_all_gather_latency_us": XGMI_LATENCY_US,
@@ -588,6 +604,8 @@ def main():
             sl.ctx.select_range(first, count)
             strong[str(n)] = e
         sl.ctx.set_result_mirror(sl.h_buf.data_ptr() + HDR, sl.h_buf.data_ptr())
+        if not os.environ.get("SBM_BENCH_LATENCY_SIZING"):
+            sl.ctx.set_pipeline_depth(len(slots))
         sl.run()
         fence()
 

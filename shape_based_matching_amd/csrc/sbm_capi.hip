@@ -187,6 +187,7 @@ struct sbm_ctx {
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
     int quantize_mode = 0, quantize_hs = 0; // sbm_set_quantize_mode
+    int pipeline_depth = 1;                 // sbm_set_pipeline_depth: batches the caller keeps in flight on this GPU
     int coarse_mode = coarse_mode_env();    // 0 auto, 1 four waves per item, 2 one wave per item (SBM_COARSE=block|wave: A/B knob)
     bool graph_mode = false; // measured on ROCm 7.2 / MI355X: graph replay is slower than stream launches
     hipStream_t side = nullptr;
@@ -398,7 +399,11 @@ int quantize_stream_rows(const sbm_ctx* c, int rows, int cols, int ch, int frame
     const bool band = band_rows > 0 && band_rows < rows;
     const int out_rows = band ? band_rows : rows;
     static const char* env = getenv("SBM_QUANTIZE");
-    static const int env_hs = getenv("SBM_QS_HS") ? atoi(getenv("SBM_QS_HS")) : 0;
+    // SBM_QS_HS=a[,b]: rows per work item, a for launches of >= 1 Mpixel per frame, b (default a) for smaller levels
+    static const char* env_hs_s = getenv("SBM_QS_HS");
+    static const int env_hs0 = env_hs_s ? atoi(env_hs_s) : 0;
+    static const int env_hs1 = env_hs_s && strchr(env_hs_s, ',') ? atoi(strchr(env_hs_s, ',') + 1) : env_hs0;
+    const int env_hs = (int64_t)rows * cols >= (1 << 20) ? env_hs0 : env_hs1;
     const int mode = c->quantize_mode ? c->quantize_mode : (env && !strcmp(env, "tile") ? 1 : (env && !strcmp(env, "stream") ? 2 : 0));
     const int force_hs = c->quantize_hs ? c->quantize_hs : env_hs;
     if (wf || (mode == 1 && !band) || cols < 4 || (cols & 3) || (int64_t)rows * cols >= (int64_t)0x7ff00000) return 0;
@@ -417,10 +422,25 @@ int quantize_stream_rows(const sbm_ctx* c, int rows, int cols, int ch, int frame
     int hs = 0;
     int64_t best = INT64_MAX;
     // a work item runs whole groups of 7 row iterations (sbm_quantize_stream.h): rows + 10 warm-up / drain, rounded up
-    for (int h = 4; h <= 130; h += 2) {
-        const int64_t waves = per_rb * ((out_rows + h - 1) / h);
-        const int64_t cost = ((waves + slots - 1) / slots) * ((std::min(h, out_rows) + 10 + 6) / 7 * 7);
-        if (cost <= best) best = cost, hs = h;
+    if (c->pipeline_depth >= 2) {
+        // Throughput sizing (the caller keeps several batches in flight on other streams / contexts, sbm_set_pipeline_depth):
+        // what matters is the launch's TOTAL work, waves x row iterations -- the 10 warm-up / drain rows of every work item
+        // are pure overhead, so fewer, longer items -- and not that one launch alone fills every SIMD: the other batches'
+        // kernels take the SIMDs this one leaves idle.  Items longer than 42 iterations stopped paying in the measurement
+        // (profiles/r03_rows_per_item_sweep.txt: 16 x 1024^2 x 3, three batches in flight, us per step: 126.0 with the
+        // latency sizing 24 / 10 rows, 116.4 with 32 / 32, 122.0 with 46 / 46, 137 with 60 / 60).
+        for (int h = 4; h <= 32; h += 2) {
+            const int64_t waves = per_rb * ((out_rows + h - 1) / h);
+            const int64_t cost = waves * ((std::min(h, out_rows) + 10 + 6) / 7 * 7);
+            if (cost <= best) best = cost, hs = h;
+        }
+    } else {
+        // Latency sizing: every work item resident at once, as few row iterations as that allows
+        for (int h = 4; h <= 130; h += 2) {
+            const int64_t waves = per_rb * ((out_rows + h - 1) / h);
+            const int64_t cost = ((waves + slots - 1) / slots) * ((std::min(h, out_rows) + 10 + 6) / 7 * 7);
+            if (cost <= best) best = cost, hs = h;
+        }
     }
     // small launches: the 16 x 64 tiles of k_quantize finish sooner than a few long serial chains
     if (!band && mode != 2 && (int64_t)rows * cols * frames < ((int64_t)4 << 20)) return 0;
@@ -1419,6 +1439,14 @@ int sbm_set_quantize_mode(sbm_ctx* c, int32_t mode, int32_t rows_per_wave)
     c->quantize_mode = mode;
     c->quantize_hs = rows_per_wave;
     c->drop_graphs(); // captured launches hold the old kernel choice
+    return 0;
+}
+
+int sbm_set_pipeline_depth(sbm_ctx* c, int32_t batches_in_flight)
+{
+    if (!c || batches_in_flight < 1) return fail(SBM_ERR_INVALID, "bad pipeline depth");
+    c->pipeline_depth = batches_in_flight;
+    c->drop_graphs(); // captured launches hold the old launch geometry
     return 0;
 }
 
