@@ -112,7 +112,8 @@ struct sbm_ctx {
     std::vector<int32_t> h_class, h_tid;
     std::vector<int32_t> h_active;
     DevBuf d_tls, d_fxy, d_flabel, d_flevel, d_foff, d_class, d_tid, d_active, d_rawmin, d_rawkeep;
-    DevBuf d_citems, d_cfoff; // coarse pass: one record + the first 64 feature offsets per active template (k_prep_coarse_items)
+    DevBuf d_citems, d_cfoff, d_soff, d_soffbase; // coarse pass: per active template one record, its feature offsets sorted by byte
+                                                   // misalignment, the first 64 of them again by slot (k_prep_coarse_items)
     bool citems_dirty = true;
     DevBuf d_fxy_s, d_flabel_s, d_fcls; // refinement pass on the strip plane: features sorted by (x / T) & 15 per template level + 17 class offsets
     bool have_thr = false;
@@ -649,10 +650,20 @@ int ensure_citems(sbm_ctx* c, hipStream_t s)
     const int lc = c->L - 1, T = c->cfg.T[lc], W = c->cols[lc] / T, H = c->rows[lc] / T;
     if (int e = c->d_citems.ensure((size_t)n_active * sizeof(CoarseItem))) return e;
     if (int e = c->d_cfoff.ensure((size_t)n_active * 64 * 4)) return e;
+    std::vector<int32_t> base((size_t)n_active);
+    int64_t total = 0;
+    for (int i = 0; i < n_active; ++i) {
+        base[i] = (int32_t)total;
+        total += c->h_tls[(size_t)c->h_active[i] * c->L + lc].nf;
+    }
+    if (total >= (int64_t)INT32_MAX) return fail(SBM_ERR_INVALID, "too many coarse-level features in the selection");
+    if (int e = c->d_soff.ensure((size_t)std::max<int64_t>(total, 1) * 4)) return e;
+    if (int e = c->d_soffbase.ensure((size_t)n_active * 4)) return e;
+    HIP_TRY(hipMemcpyAsync(c->d_soffbase.p, base.data(), (size_t)n_active * 4, hipMemcpyHostToDevice, s));
     const int zero_off = (int)(7 * c->lm_stride[lc] + (int64_t)T * T * W * H);
-    hipLaunchKernelGGL(k_prep_coarse_items, dim3((unsigned)std::min(n_active, 4096)), dim3(256), 0, s, c->d_active.as<int32_t>(), n_active,
-                       c->d_tls.as<DevTL>(), c->L, lc, c->d_rawmin.as<int32_t>(), c->d_foff.as<int32_t>(), T, W, H, zero_off,
-                       c->d_citems.as<CoarseItem>(), c->d_cfoff.as<int32_t>());
+    hipLaunchKernelGGL(k_prep_coarse_items, dim3((unsigned)((n_active + 63) / 64)), dim3(64), 0, s, c->d_active.as<int32_t>(), n_active,
+                       c->d_tls.as<DevTL>(), c->L, lc, c->d_rawmin.as<int32_t>(), c->d_foff.as<int32_t>(), c->d_soffbase.as<int32_t>(), T, W, H,
+                       zero_off, c->d_citems.as<CoarseItem>(), c->d_soff.as<int32_t>(), c->d_cfoff.as<int32_t>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s)); // consumers may run on another stream (as ensure_foff)
     c->citems_dirty = false;
@@ -833,7 +844,7 @@ int enqueue_coarse(sbm_ctx* c, hipStream_t s, sbm_match_rec* d_out, int64_t cap,
             if (per_wave)
                 SBM_LAUNCH(c, "k_similarity_coarse", k_similarity_coarse_wave, dim3(chunks, (cnt + 3) / 4, frames), dim3(256), 0, s,
                            c->d_lm[lc].as<uint8_t>(), c->lm_stride[lc], c->rows[lc], c->cols[lc], T, W, H, L, lc, c->d_tls.as<DevTL>(),
-                           c->d_foff.as<int32_t>(), c->d_citems.as<CoarseItem>() + first, c->d_cfoff.as<int32_t>() + (size_t)first * 64, cnt,
+                           c->d_soff.as<int32_t>(), c->d_citems.as<CoarseItem>() + first, c->d_cfoff.as<int32_t>() + (size_t)first * 64, cnt,
                            c->d_rawkeep.as<int32_t>(), c->d_class.as<int32_t>(), c->d_tid.as<int32_t>(),
                            c->d_cands.as<Cand>(), counters, (int)c->cand_cap, (int64_t)8 * c->lm_stride[lc]);
             else
@@ -1087,7 +1098,7 @@ void sbm_destroy(sbm_ctx* c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side) (void)hipStreamDestroy(c->side);
     c->clear_timings();
-    DevBuf* singles[] = {&c->d_tls, &c->d_fxy, &c->d_flabel, &c->d_flevel, &c->d_foff, &c->d_class, &c->d_tid, &c->d_active, &c->d_citems, &c->d_cfoff, &c->d_fxy_s, &c->d_flabel_s, &c->d_fcls,
+    DevBuf* singles[] = {&c->d_tls, &c->d_fxy, &c->d_flabel, &c->d_flevel, &c->d_foff, &c->d_class, &c->d_tid, &c->d_active, &c->d_citems, &c->d_cfoff, &c->d_soff, &c->d_soffbase, &c->d_fxy_s, &c->d_flabel_s, &c->d_fcls,
                          &c->d_rawmin, &c->d_rawkeep, &c->d_geo, &c->d_cands, &c->d_counters, &c->d_out, &c->d_outcount,
                          &c->d_scratch};
     for (DevBuf* b : singles) b->release();

@@ -1129,33 +1129,46 @@ __global__ __launch_bounds__(256) void k_prep_features(const uint32_t* __restric
 }
 
 // What one work item of the coarse pass needs about its template, in one 32-byte record (one scalar load instead of
-// the chain active[] -> tls[] -> raw_min[]), and the offsets of the template's first 64 coarsest-level features,
-// indexed by the item's slot (a vector load that does not wait for the record).
+// the chain active[] -> tls[] -> raw_min[]), and the template's coarsest-level feature offsets SORTED BY THEIR BYTE
+// MISALIGNMENT (offset & 3): features of one class are summed as raw dwords and re-aligned once per batch instead of
+// once per feature (a sum does not care about the order of its terms).  e01 / e2: where classes 0, 1, 2 end in the
+// sorted list (class 3 ends at nf).  cfoff: the first 64 sorted offsets, indexed by the item's slot (a vector load that
+// does not wait for the record).
 struct CoarseItem {
-    int32_t t, feat_off, nf, npos, rmin, pad0, pad1, pad2;
+    int32_t t, soff_base, nf, npos, rmin, e01, e2, pad;
 };
-__global__ __launch_bounds__(256) void k_prep_coarse_items(const int32_t* __restrict__ active, int n_active, const DevTL* __restrict__ tls,
-                                                           int L, int lc, const int32_t* __restrict__ raw_min,
-                                                           const int32_t* __restrict__ foff, int T, int W, int H, int zero_off,
-                                                           CoarseItem* __restrict__ items, int32_t* __restrict__ cfoff)
+__global__ __launch_bounds__(64) void k_prep_coarse_items(const int32_t* __restrict__ active, int n_active, const DevTL* __restrict__ tls,
+                                                          int L, int lc, const int32_t* __restrict__ raw_min,
+                                                          const int32_t* __restrict__ foff, const int32_t* __restrict__ soff_base,
+                                                          int T, int W, int H, int zero_off, CoarseItem* __restrict__ items,
+                                                          int32_t* __restrict__ soff, int32_t* __restrict__ cfoff)
 {
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n_active * 64; idx += gridDim.x * 256) {
-        const int slot = idx >> 6, i = idx & 63;
-        const int t = active[slot];
-        const DevTL tl = tls[(size_t)t * L + lc];
-        cfoff[idx] = i < tl.nf ? foff[tl.feat_off + i] : zero_off;
-        if (i == 0) {
-            const int wf = (tl.width - 1) / T + 1, hf = (tl.height - 1) / T + 1;
-            CoarseItem it;
-            it.t = t;
-            it.feat_off = tl.feat_off;
-            it.nf = tl.nf;
-            it.npos = (H - hf) * W + (W - wf) + 1;
-            it.rmin = raw_min[(size_t)t * L + lc];
-            it.pad0 = it.pad1 = it.pad2 = 0;
-            items[slot] = it;
-        }
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= n_active) return;
+    const int t = active[slot];
+    const DevTL tl = tls[(size_t)t * L + lc];
+    const int32_t* f = foff + tl.feat_off;
+    int32_t* out = soff + soff_base[slot];
+    int cnt[4] = {0, 0, 0, 0};
+    for (int i = 0; i < tl.nf; ++i) ++cnt[f[i] & 3];
+    int pos[4] = {0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2]};
+    const int e0 = pos[1], e1 = pos[2], e2 = pos[3];
+    for (int i = 0; i < tl.nf; ++i) { // stable counting sort over the four classes
+        const int o = f[i];
+        out[pos[o & 3]++] = o;
     }
+    for (int i = 0; i < 64; ++i) cfoff[(size_t)slot * 64 + i] = i < tl.nf ? out[i] : zero_off;
+    const int wf = (tl.width - 1) / T + 1, hf = (tl.height - 1) / T + 1;
+    CoarseItem it;
+    it.t = t;
+    it.soff_base = soff_base[slot];
+    it.nf = tl.nf;
+    it.npos = (H - hf) * W + (W - wf) + 1;
+    it.rmin = raw_min[(size_t)t * L + lc];
+    it.e01 = e0 | (e1 << 16);
+    it.e2 = e2;
+    it.pad = 0;
+    items[slot] = it;
 }
 
 __device__ __forceinline__ int template_positions(const DevTL& tl, int W, int H, int T)
@@ -1349,18 +1362,25 @@ __device__ __forceinline__ uint32_t coarse_pk_max_u16(uint32_t a, uint32_t b) //
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(coarse_us2, a), __builtin_bit_cast(coarse_us2, b)));
 }
 
-// accumulate_features16 with exact pruning, for a wave that owns ALL nf features of its item.  A feature adds at
-// most 4, so once `done` features are in, a position whose partial sum is below rmin - 4*(nf - done) cannot reach
-// rmin any more; after every batch of 8 features (as soon as that bound exceeds half the prefix's own maximum
-// 4*done -- a weaker bound prunes little and rmin <= 2*nf never gets there) the wave looks whether any of its 1024
-// positions is still alive and returns false if none is.  Positions past the template's span may hold anything:
-// they can only keep the wave going, the caller's scan ignores them.  Returns true with the complete sums.
-// foff: the template's coarsest-level feature offsets with the out-of-image test already folded in (k_prep_features:
-// such a feature points at the zero tail); sel0: the first 64 of them, loaded by the caller before it knew the template
-// record (k_prep_coarse_items: lanes past nf hold the zero tail's offset).
-__device__ __forceinline__ bool accumulate_features16_pruned(const uint8_t* __restrict__ lm, const int32_t* __restrict__ foff, int sel0,
-                                                             int nf, int j0, bool lane_on, int zero_off, int rmin,
-                                                             uint32_t (&lo)[4], uint32_t (&hi)[4])
+// The coarse pass of a wave that owns ALL nf features of its item, with exact pruning.
+//
+// Pruning: a feature adds at most 4, so once `done` features are in, a position whose partial sum is below
+// rmin - 4*(nf - done) cannot reach rmin any more; after every batch the wave looks whether any of its 1024 positions is
+// still alive and returns false if none is.  Positions past the template's span may hold anything: they can only keep
+// the wave going, the caller's scan ignores them.  Returns true with the complete sums.
+//
+// Round 3: the feature offsets arrive sorted by byte misalignment (k_prep_coarse_items), a batch (up to 8 features)
+// never crosses a class boundary, and its features are summed as RAW dwords -- the 16 bytes at the 4-byte-aligned
+// address, the dword after them (lane 63 loads it, every other lane takes its right neighbour's first dword: a lane
+// permutation commutes with the sum, so ONE DPP move per batch) -- then re-aligned once (4 v_alignbyte per batch instead
+// of per feature).  While no position can exceed 255 (<= 60 features) the totals stay packed bytes and the aliveness test
+// is a carry-free byte trick: with K = 128 - bound, byte + K has its top bit set iff byte >= bound, and byte + K never
+// exceeds 128 + (4 nf - rmin) (needs 4 nf - rmin <= 127: thresholds of ~70 % and up at 128 features; below that, and
+// once a bound passes 128, the sums are widened to packed u16 as before).
+// soff: the template's sorted offsets (out-of-image features point at the zero tail); sel0: the first 64 of them.
+__device__ __forceinline__ bool accumulate_features16_pruned(const uint8_t* __restrict__ lm, const int32_t* __restrict__ soff, int sel0,
+                                                             int nf, int e0, int e1, int e2, int j0, bool lane_on, int zero_off,
+                                                             int rmin, uint32_t (&lo)[4], uint32_t (&hi)[4])
 {
     const int lane = threadIdx.x & 63;
     const uint8_t* p = lm + j0;
@@ -1368,63 +1388,88 @@ __device__ __forceinline__ bool accumulate_features16_pruned(const uint8_t* __re
     for (int i = 0; i < 4; ++i) lo[i] = hi[i] = 0;
     nf = __builtin_amdgcn_readfirstlane(nf);
     rmin = __builtin_amdgcn_readfirstlane(rmin);
-    for (int b = 0; b < nf; b += 64) {
-        int sel = sel0;
-        if (b > 0) sel = b + lane < nf ? foff[b + lane] : zero_off;
-        const int nb = nf - b < 64 ? nf - b : 64;
-        auto batch = [&](auto N, int u) {
-            constexpr int n = decltype(N)::value;
-            u128_a4 q[n];
-            uint32_t e[n];
-            int sh[n];
+    e0 = __builtin_amdgcn_readfirstlane(e0);
+    e1 = __builtin_amdgcn_readfirstlane(e1);
+    e2 = __builtin_amdgcn_readfirstlane(e2);
+    const int slack = 4 * nf - rmin;
+    uint32_t acc8[4] = {0, 0, 0, 0}; // packed-byte totals of the features since the last widening
+    int in8 = 0;                     // features in acc8
+    int sel = sel0;
+    int g = 0;
+    while (g < nf) {
+        if (g && (g & 63) == 0) sel = g + lane < nf ? soff[g + lane] : zero_off; // next 64 offsets
+        const int cls = g < e0 ? 0 : (g < e1 ? 1 : (g < e2 ? 2 : 3));
+        const int cend = cls == 0 ? e0 : (cls == 1 ? e1 : (cls == 2 ? e2 : nf));
+        int lim = cend - g;                 // features left in this class ...
+        const int chunk_left = 64 - (g & 63); // ... and in this 64-offset chunk
+        lim = lim < chunk_left ? lim : chunk_left;
+        uint32_t raw[5] = {0, 0, 0, 0, 0};
+        int n = 0;
+        auto batch = [&](auto N) {
+            constexpr int nn = decltype(N)::value;
             if (lane_on) {
+                u128_a4 q[nn];
+                uint32_t e[nn];
 #pragma unroll
-                for (int k = 0; k < n; ++k) {
-                    const int o = __builtin_amdgcn_readlane(sel, (u + k) & 63);
-                    sh[k] = o & 3;
+                for (int k = 0; k < nn; ++k) {
+                    const int o = __builtin_amdgcn_readlane(sel, (g + k) & 63);
                     const uint8_t* a = p + (o & ~3);
                     q[k] = *(const u128_a4*)a;
                     e[k] = 0;
                     if (lane == 63) e[k] = *(const uint32_t*)(a + 16);
                 }
-            } else {
 #pragma unroll
-                for (int k = 0; k < n; ++k) {
-                    q[k] = u128_a4{0, 0, 0, 0};
-                    e[k] = 0;
-                    sh[k] = 0;
+                for (int k = 0; k < nn; ++k) { // <= 8 addends of <= 4: no carry between the bytes
+                    raw[0] += q[k].x;
+                    raw[1] += q[k].y;
+                    raw[2] += q[k].z;
+                    raw[3] += q[k].w;
+                    raw[4] += e[k];
                 }
             }
-            uint32_t acc[4] = {0, 0, 0, 0}; // byte sums of at most 8 features
-#pragma unroll
-            for (int k = 0; k < n; ++k) {
-                const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)e[k], (int)q[k].x, 0x130, 0xf, 0xf, false);
-                acc[0] += __builtin_amdgcn_alignbyte(q[k].y, q[k].x, sh[k]);
-                acc[1] += __builtin_amdgcn_alignbyte(q[k].z, q[k].y, sh[k]);
-                acc[2] += __builtin_amdgcn_alignbyte(q[k].w, q[k].z, sh[k]);
-                acc[3] += __builtin_amdgcn_alignbyte(nx, q[k].w, sh[k]);
-            }
+            n = nn;
+        };
+        if (lim >= FB16) batch(std::integral_constant<int, FB16>{});
+        else if (lim >= 4) batch(std::integral_constant<int, 4>{});
+        else if (lim >= 2) batch(std::integral_constant<int, 2>{});
+        else batch(std::integral_constant<int, 1>{});
+        // the dword after the lane's 16 bytes: the right neighbour's first dword (lane 63: what it loaded itself)
+        const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)raw[4], (int)raw[0], 0x130, 0xf, 0xf, false);
+        acc8[0] += __builtin_amdgcn_alignbyte(raw[1], raw[0], cls);
+        acc8[1] += __builtin_amdgcn_alignbyte(raw[2], raw[1], cls);
+        acc8[2] += __builtin_amdgcn_alignbyte(raw[3], raw[2], cls);
+        acc8[3] += __builtin_amdgcn_alignbyte(nx, raw[3], cls);
+        g += n;
+        in8 += n;
+        const int bound = rmin - 4 * (nf - g);
+        const bool test = bound > 0 && g < nf;
+        const bool in_bytes = test && slack <= 127 && bound <= 128 && in8 == g; // nothing widened yet: the totals are the packed bytes
+        if (in_bytes) {
+            const uint32_t K = (uint32_t)(128 - bound) * 0x01010101u; // byte + K <= 128 + slack: no carry between the bytes
+            const uint32_t hit = ((acc8[0] + K) | (acc8[1] + K) | (acc8[2] + K) | (acc8[3] + K)) & 0x80808080u;
+            if (__builtin_amdgcn_ballot_w64(hit != 0u) == 0ull) return false;
+        }
+        if ((test && !in_bytes) || in8 > 52) {
+            // widen: packed bytes into the packed-u16 totals (a byte may hold up to 4 * 60)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                lo[i] += acc[i] & 0x00ff00ffu;
-                hi[i] += (acc[i] >> 8) & 0x00ff00ffu;
+                lo[i] += acc8[i] & 0x00ff00ffu;
+                hi[i] += (acc8[i] >> 8) & 0x00ff00ffu;
+                acc8[i] = 0;
             }
-        };
-        int u = 0;
-        for (; u + FB16 <= nb; u += FB16) {
-            batch(std::integral_constant<int, FB16>{}, u);
-            const int done = b + u + FB16;
-            const int bound = rmin - 4 * (nf - done);
-            if (bound > 0 && done < nf) {
+            in8 = 0;
+            if (test && !in_bytes) {
                 const uint32_t m = coarse_pk_max_u16(coarse_pk_max_u16(coarse_pk_max_u16(lo[0], hi[0]), coarse_pk_max_u16(lo[1], hi[1])),
                                                      coarse_pk_max_u16(coarse_pk_max_u16(lo[2], hi[2]), coarse_pk_max_u16(lo[3], hi[3])));
                 const int best = (int)((m & 0xffff) > (m >> 16) ? (m & 0xffff) : (m >> 16));
                 if (__builtin_amdgcn_ballot_w64(best >= bound) == 0ull) return false;
             }
         }
-        if (nb - u >= 4) { batch(std::integral_constant<int, 4>{}, u); u += 4; }
-        if (nb - u >= 2) { batch(std::integral_constant<int, 2>{}, u); u += 2; }
-        if (nb - u >= 1) batch(std::integral_constant<int, 1>{}, u);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lo[i] += acc8[i] & 0x00ff00ffu;
+        hi[i] += (acc8[i] >> 8) & 0x00ff00ffu;
     }
     return true;
 }
@@ -1598,7 +1643,7 @@ __global__ __launch_bounds__(256) void k_similarity_coarse(
 // single-frame latency low) only multiplies the per-item overhead.  Same arguments, same candidates.
 __global__ __launch_bounds__(256) void k_similarity_coarse_wave(
     const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int lc,
-    const DevTL* __restrict__ tls, const int32_t* __restrict__ foff, const CoarseItem* __restrict__ items,
+    const DevTL* __restrict__ tls, const int32_t* __restrict__ soff, const CoarseItem* __restrict__ items,
     const int32_t* __restrict__ cfoff, int n_active, const int32_t* __restrict__ raw_keep,
     const int32_t* __restrict__ class_idx, const int32_t* __restrict__ template_id, Cand* __restrict__ cands,
     int32_t* __restrict__ counters, int cap, int64_t lm_fs)
@@ -1628,7 +1673,8 @@ __global__ __launch_bounds__(256) void k_similarity_coarse_wave(
     if (base < npos) {
         const int zero_off = (int)(7 * lm_stride + (int64_t)T * T * W * H);
         const bool lane_on = j0 < npos + 16;
-        if (!accumulate_features16_pruned(lm, foff + it.feat_off, sel0, it.nf, lane_on ? j0 : 0, lane_on, zero_off, rmin, lo, hi))
+        if (!accumulate_features16_pruned(lm, soff + it.soff_base, sel0, it.nf, it.e01 & 0xffff, (int)((uint32_t)it.e01 >> 16), it.e2,
+                                          lane_on ? j0 : 0, lane_on, zero_off, rmin, lo, hi))
             return; // no position of this item can reach rmin
     }
     const int offset = T / 2 + (T % 2 - 1);
