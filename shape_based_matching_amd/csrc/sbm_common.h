@@ -1,0 +1,60 @@
+// sbm_common.h — types shared by the gfx950 kernels of the engine (per-template records, candidate records, load types).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "../../include/sbm_types.h"
+#include "sbm_resize_table.h"
+
+namespace sbm {
+
+// per (template, level) record on the device
+struct DevTL {
+    int32_t width, height, nf, feat_off;
+};
+// coarse candidate / refinement state (Match under construction)
+// Carries everything the NEXT refinement pass needs (the template record of that level, its keep
+// threshold, the ids of the final Match), so that pass starts its feature loads after one
+// dependent read instead of three.
+struct Cand {
+    int32_t t;   // template index (into the uploaded list)
+    int32_t x;   // Match::x at the level just processed
+    int32_t y;
+    int32_t raw; // integer similarity sum; < 0 = dropped by the per-level filter
+    int32_t next_width, next_height, next_nf, next_feat_off; // DevTL of the level refined next
+    int32_t next_keep;                                       // raw_keep of that level
+    int32_t class_idx, template_id;
+    int32_t pad;
+};
+static_assert(sizeof(Cand) == 48, "Cand layout");
+
+__device__ __forceinline__ void cand_fill_next(Cand& c, const DevTL* __restrict__ tls, const int32_t* __restrict__ raw_keep,
+                                               const int32_t* __restrict__ class_idx, const int32_t* __restrict__ template_id,
+                                               int L, int next_level)
+{
+    if (next_level >= 0) {
+        const DevTL tn = tls[(size_t)c.t * L + next_level];
+        c.next_width = tn.width;
+        c.next_height = tn.height;
+        c.next_nf = tn.nf;
+        c.next_feat_off = tn.feat_off;
+        c.next_keep = raw_keep[(size_t)c.t * L + next_level];
+    }
+    c.class_idx = class_idx[c.t];
+    c.template_id = template_id[c.t];
+    c.pad = 0;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+__device__ __forceinline__ uint32_t ld_u32_any(const uint8_t* p) { return *(const u32_unaligned*)p; }
+struct __attribute__((aligned(4))) u128_a4 { uint32_t x, y, z, w; }; // 16-byte load at 4-byte alignment
+
+} // namespace sbm

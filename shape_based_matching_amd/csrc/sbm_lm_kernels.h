@@ -1,0 +1,350 @@
+// sbm_lm_kernels.h — gfx950 kernels that turn a one-hot orientation map into linear memories.
+// Reference functions replaced (file:line in ddcr/shape_based_matching):
+//   k_build_lm_rows / k_build_lm   spread + computeResponseMaps + linearize, fused   line2Dup.cpp:616-630, 637-747, 749-777
+//   k_spread / k_response / k_linearize   the same three, unfused (stage entry points)
+//   k_expand_lm           the 8-plane form of a compact (spread-byte) level, on demand
+#pragma once
+#include "sbm_common.h"
+
+namespace sbm {
+
+// ---------------------------------------------------------------------------
+// Linear memories: spread + response + linearize fused
+// ---------------------------------------------------------------------------
+constexpr int LM_GX = 64; // grid cells per block along x
+
+// response of 4 packed spread bytes for orientation o: 4 if bit o set, else 3
+// if a circular neighbour bit is set, else 0 (== SIMILARITY_LUT, line2Dup.cpp:635)
+__device__ __forceinline__ uint32_t response4(uint32_t v, int o)
+{
+    uint32_t self = (v >> o) & 0x01010101u;
+    uint32_t nb = ((v >> ((o + 1) & 7)) | (v >> ((o + 7) & 7))) & 0x01010101u & ~self;
+    return (self << 2) | (nb * 3u);
+}
+
+// One block = one row of grid cells (T pixel rows) x 64 cells.  The one-hot
+// tile (+T-1 halo, zero outside the image = the clipped window of spread())
+// is OR-reduced separably in LDS, stored there already in linear-memory order
+// [ty][tx][gx], then each lane turns 4 consecutive cells into the 8
+// orientation responses and writes 8 dwords, coalesced along gx.
+__global__ __launch_bounds__(256) void k_build_lm(const uint8_t* __restrict__ q, int rows, int cols, int T,
+                                                  int W, int H, uint8_t* __restrict__ lm, int64_t lm_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int gx0 = blockIdx.x * LM_GX, gy = blockIdx.y;
+    const int tw = LM_GX * T;      // tile width in pixels
+    const int lw = tw + T - 1;     // + halo
+    const int lwp = (lw + 3) & ~3; // padded row pitch
+    const int lh = 2 * T - 1;
+    uint8_t* s_q = smem;                  // [lh][lwp]
+    uint8_t* s_h = s_q + lh * lwp;        // [lh][tw]   horizontal OR
+    uint8_t* s_sp = s_h + lh * tw;        // [T*T][LM_GX] spread, linearized order
+    const int pr0 = gy * T, pc0 = gx0 * T;
+    for (int idx = tid; idx < lh * lwp; idx += 256) {
+        int r = idx / lwp, c = idx - r * lwp;
+        int gr = pr0 + r, gc = pc0 + c;
+        s_q[idx] = (c < lw && gr < rows && gc < cols) ? q[(size_t)gr * cols + gc] : (uint8_t)0;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < lh * tw; idx += 256) {
+        int r = idx / tw, c = idx - r * tw;
+        uint8_t v = 0;
+        for (int d = 0; d < T; ++d) v |= s_q[r * lwp + c + d];
+        s_h[idx] = v;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < T * tw; idx += 256) {
+        int ty = idx / tw, c = idx - ty * tw;
+        uint8_t v = 0;
+        for (int d = 0; d < T; ++d) v |= s_h[(ty + d) * tw + c];
+        int g = c / T, tx = c - g * T;
+        s_sp[(ty * T + tx) * LM_GX + g] = v;
+    }
+    __syncthreads();
+    const int64_t WH = (int64_t)W * H;
+    const int items = T * T * (LM_GX / 4);
+    const bool fast = (W & 3) == 0;
+    for (int it = tid; it < items; it += 256) {
+        int sub = it / (LM_GX / 4), g4 = it - sub * (LM_GX / 4);
+        int gx = gx0 + g4 * 4;
+        if (gx >= W) continue;
+        uint32_t v = ((const uint32_t*)s_sp)[sub * (LM_GX / 4) + g4];
+        int64_t dst = (int64_t)sub * WH + (int64_t)gy * W + gx;
+        if (fast) {
+#pragma unroll
+            for (int o = 0; o < 8; ++o) *(uint32_t*)(lm + o * lm_stride + dst) = response4(v, o);
+        } else {
+            for (int o = 0; o < 8; ++o) {
+                uint32_t rsp = response4(v, o);
+                for (int k = 0; k < 4 && gx + k < W; ++k) lm[o * lm_stride + dst + k] = (uint8_t)(rsp >> (8 * k));
+            }
+        }
+    }
+}
+
+// Strip-interleaved compact plane of a refinement-only level (needs W % 16 == 0): inside sub-plane
+// sub = (y%T)*T + x%T the W x H grid is cut into W/16 column strips of 16 cells, and a strip is stored row after
+// row, 16 bytes per row:  offset = sub*W*H + ((gx / 16) * H + gy) * 16 + gx % 16.
+// similarityLocal (line2Dup.cpp:860-922) reads 16 x 16 cells per feature; row-major that is 16 pieces of 16 bytes in
+// 16 different 128-byte lines, here it is two runs of 256 contiguous bytes at most (one when gx % 16 == 0).
+__host__ __device__ __forceinline__ int64_t lm_strip_offset(int sub, int gy, int gx, int W, int H)
+{
+    return (int64_t)sub * W * H + ((int64_t)(gx >> 4) * H + gy) * 16 + (gx & 15);
+}
+
+// ---- register-only variant for T = 4 and T = 8 (the reference's strides) ----
+// One lane owns 4 consecutive grid cells (4*T pixels) of one (ty, gy) pixel row
+// r0 = gy*T + ty: it ORs the T source rows r0..r0+T-1 (16-byte loads), ORs T
+// pixels forward with funnel shifts, transposes the 4 cells x T sub-columns in
+// registers (v_perm), and for every tx and orientation stores one dword =
+// responses of cells gx..gx+3.  A wave's store is one contiguous run of
+// LM[o][ty*T+tx][gy*W + ...]: no LDS, no barrier, fully coalesced.
+// Requires W % 4 == 0 and cols % 16 == 0 (host checks; else k_build_lm).
+__device__ __forceinline__ uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    return __builtin_amdgcn_perm(hi, lo, sel);
+}
+
+constexpr int LM_FULL_SPLIT = 4; // work items per (pixel row, 4 cells) of a level stored as 8 response planes
+
+template <int T>
+__device__ __forceinline__ void build_lm_rows_item(const uint8_t* __restrict__ q, int rows, int cols, int W, int H,
+                                                   uint8_t* __restrict__ lm, int64_t lm_stride, int64_t item,
+                                                   int compact, int split, uint32_t* s_tile)
+{
+    constexpr int NQ = T / 4 * 4; // dwords of own pixels per lane (4 cells * T px / 4)
+    int r0, k, part = 0;
+    bool active = true; // strip mode: every thread of the workgroup reaches the barrier below
+    int tile_cb = 0, tile_gyb = 0, tile_ty = 0;
+    if (compact == 2) {
+        // strip-interleaved plane: a WORKGROUP = one ty x 16 grid rows x 64 cells (4 strips).  Thread (row = t / 16,
+        // kk = t % 16) reads 4 cells of its row -- a wave's loads are 4 runs of 256 bytes -- and the spread dwords go
+        // through LDS so that wave w then stores strip w of the tile: 16 strip rows of 16 bytes = one run of 256 bytes
+        // per store.  (Round 2's first form let a wave own one strip end to end: contiguous stores, but each load
+        // gathered 64-byte pieces of 16 different rows; 14.9 us of the 16-frame launch were level 0.)
+        const int n_cb = (W + 63) >> 6, gyb_n = (H + 15) >> 4;
+        const int t = (int)(item & 255);
+        const int64_t blk = item >> 8;
+        tile_cb = (int)(blk % n_cb);
+        const int64_t rest = blk / n_cb;
+        tile_gyb = (int)(rest % gyb_n);
+        tile_ty = (int)(rest / gyb_n);
+        const int gy_ = tile_gyb * 16 + (t >> 4);
+        k = tile_cb * 16 + (t & 15);
+        active = tile_ty < T && gy_ < H && k * 4 < W;
+        r0 = active ? gy_ * T + tile_ty : 0;
+        if (!active) k = 0;
+    } else {
+        const int lanes_per_row = W >> 2;
+        int64_t it = item;
+        if (!compact && split > 1) { // LM_FULL_SPLIT items per (pixel row, 4 cells): part = (tx half, orientation half)
+            const int64_t base_items = (int64_t)rows * lanes_per_row;
+            part = (int)(item / base_items);
+            if (part >= LM_FULL_SPLIT) return;
+            it = item - part * base_items;
+        }
+        const int64_t row_id = it / lanes_per_row; // = gy * T + ty  (a pixel row index)
+        k = (int)(it - row_id * lanes_per_row);
+        if (row_id >= rows) return;
+        r0 = (int)row_id;
+    }
+    const int gy = r0 / T, ty = r0 - gy * T;
+    const int c0 = k * 4 * T; // first pixel column of this lane
+    // vertical OR of rows r0 .. r0+T-1 (clipped at the bottom, :626-627), own pixels + T px of right halo
+    uint32_t v[NQ + T / 4];
+#pragma unroll
+    for (int i = 0; i < NQ + T / 4; ++i) v[i] = 0;
+#pragma unroll
+    for (int d = 0; d < T; ++d) {
+        const int r = r0 + d;
+        if (r < rows && active) {
+            const uint8_t* src = q + (size_t)r * cols + c0;
+#pragma unroll
+            for (int i = 0; i < NQ; i += 4) {
+                const uint4 w = *(const uint4*)(src + 4 * i);
+                v[i] |= w.x;
+                v[i + 1] |= w.y;
+                v[i + 2] |= w.z;
+                v[i + 3] |= w.w;
+            }
+            if (c0 + 4 * NQ < cols) { // right halo (zero past the last column)
+#pragma unroll
+                for (int i = 0; i < T / 4; ++i) v[NQ + i] |= *(const uint32_t*)(src + 4 * (NQ + i));
+            }
+        }
+    }
+    // horizontal OR over T pixels forward: byte c |= bytes c+1 .. c+T-1
+    uint32_t s[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        uint32_t a = v[i], b = v[i + 1];
+        uint32_t o = a | __builtin_amdgcn_alignbyte(b, a, 1) | __builtin_amdgcn_alignbyte(b, a, 2) |
+                     __builtin_amdgcn_alignbyte(b, a, 3);
+        if (T == 8) {
+            uint32_t c2 = v[i + 2];
+            o |= b | __builtin_amdgcn_alignbyte(c2, b, 1) | __builtin_amdgcn_alignbyte(c2, b, 2) |
+                 __builtin_amdgcn_alignbyte(c2, b, 3);
+        }
+        s[i] = o;
+    }
+    // s[] holds 4 cells x T sub-columns; gather, per tx, the 4 cells' bytes into one dword
+    const int64_t WH = (int64_t)W * H;
+    const int64_t cell = (int64_t)gy * W + k * 4;
+    auto spread_dword = [&](int tx) {
+        // cell j lives in dwords s[j*T/4 .. ], sub-column tx is byte (tx & 3) of dword j*(T/4) + (tx >> 2)
+        const int dsel = tx >> 2, b = tx & 3;
+        const uint32_t d0 = s[0 * (T / 4) + dsel], d1 = s[1 * (T / 4) + dsel], d2 = s[2 * (T / 4) + dsel],
+                       d3 = s[3 * (T / 4) + dsel];
+        // v_perm selector bytes: 0-3 pick from 'lo', 4-7 from 'hi'
+        const uint32_t p01 = perm_b32(d1, d0, 0x0c0c0000u | ((4 + b) << 8) | b);        // {d0.b, d1.b, 0, 0}
+        const uint32_t p23 = perm_b32(d3, d2, 0x00000c0cu | ((4 + b) << 24) | (b << 16)); // {0, 0, d2.b, d3.b}
+        return p01 | p23;
+    };
+    if (compact == 2) { // strip-interleaved spread plane (lm_strip_offset): a 16 x 16 patch is 2 - 4 cache lines
+        const int t = (int)(item & 255);
+        const int kk = t & 15, row = t >> 4;
+#pragma unroll
+        for (int tx = 0; tx < T; ++tx) s_tile[tx * 256 + (kk >> 2) * 64 + row * 4 + (kk & 3)] = spread_dword(tx);
+        __syncthreads();
+        const int S = tile_cb * 4 + (t >> 6), gy2 = tile_gyb * 16 + ((t & 63) >> 2);
+        if (tile_ty < T && S < (W >> 4) && gy2 < H) {
+#pragma unroll
+            for (int tx = 0; tx < T; ++tx)
+                *(uint32_t*)(lm + lm_strip_offset(tile_ty * T + tx, gy2, S * 16 + (t & 3) * 4, W, H)) = s_tile[tx * 256 + t];
+        }
+    } else if (compact) { // one plane of spread bytes: the reader applies the response LUT for its own orientation
+#pragma unroll
+        for (int tx = 0; tx < T; ++tx) *(uint32_t*)(lm + (int64_t)(ty * T + tx) * WH + cell) = spread_dword(tx);
+    } else {
+        // 8 response planes: T * 8 dword stores per (row, 4 cells) -- 64 at T = 8, on a level with few rows.  For a
+        // single frame (split > 1) the item is cut into LM_FULL_SPLIT parts (tx half = part >> 1, orientation half =
+        // part & 1; the loads and ORs are repeated) so that the level is four times as many, four times shorter waves:
+        // 7.7 -> 6.9 us.  A batch of frames has enough waves and only pays the repeats (23 -> 25 us): split = 1.
+        if (split > 1) {
+            const int txh = part >> 1, o0 = (part & 1) * 4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h != txh) continue;
+#pragma unroll
+                for (int t = 0; t < T / 2; ++t) {
+                    const int tx = h * (T / 2) + t;
+                    const uint32_t sp = spread_dword(tx);
+                    const int64_t dst = (int64_t)(ty * T + tx) * WH + cell;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) *(uint32_t*)(lm + (o0 + o) * lm_stride + dst) = response4(sp, o0 + o);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int tx = 0; tx < T; ++tx) {
+                const uint32_t sp = spread_dword(tx);
+                const int64_t dst = (int64_t)(ty * T + tx) * WH + cell;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) *(uint32_t*)(lm + o * lm_stride + dst) = response4(sp, o);
+            }
+        }
+    }
+}
+
+// All pyramid levels in one launch: block ranges per level (levels whose T is 4 or 8), plus the
+// reset of the per-frame counters, so the whole linear-memory stage costs one kernel boundary.
+struct LmLevelArgs {
+    const uint8_t* q;
+    uint8_t* lm;
+    int64_t lm_stride;
+    int32_t rows, cols, W, H, T;
+    int32_t block_begin; // first block of this level
+    int64_t q_fs, lm_fs; // bytes from one frame of a batch to the next
+    int32_t compact;     // 1: lm is ONE plane [T*T][W*H] of spread bytes (a level that only the refinement pass
+                         // reads): 1/8 of the stores and of the HBM write-back; 2: the same plane strip-interleaved
+    int32_t split;       // 8-plane levels: LM_FULL_SPLIT work items per (pixel row, 4 cells) instead of 1
+};
+struct LmArgs {
+    LmLevelArgs lv[SBM_MAX_LEVELS];
+    int32_t n_levels;
+    int32_t* counters;  // may be null
+    int32_t* out_count; // may be null
+};
+
+__global__ __launch_bounds__(256) void k_build_lm_rows(const LmArgs a)
+{
+    __shared__ uint32_t s_tile[8 * 256]; // strip levels: the workgroup's spread dwords, [tx][strip][row][4 cells]
+    const size_t frame = blockIdx.y; // batch of frames: one grid row each
+    if (blockIdx.x == 0 && a.counters) {
+        if (threadIdx.x < 40) a.counters[frame * 40 + threadIdx.x] = 0;
+        if (threadIdx.x < 2 && a.out_count) a.out_count[frame * 2 + threadIdx.x] = 0;
+    }
+    // the level whose block range holds this block (the host orders the ranges heaviest blocks first)
+    int l = 0, lb = -1;
+#pragma unroll
+    for (int i = 0; i < SBM_MAX_LEVELS; ++i)
+        if (i < a.n_levels && (int)blockIdx.x >= a.lv[i].block_begin && a.lv[i].block_begin > lb) l = i, lb = a.lv[i].block_begin;
+    const LmLevelArgs& p = a.lv[l];
+    const int64_t item = (int64_t)((int)blockIdx.x - p.block_begin) * 256 + threadIdx.x;
+    const uint8_t* q = p.q + frame * p.q_fs;
+    uint8_t* lm = p.lm + frame * p.lm_fs;
+    if (p.T == 4) build_lm_rows_item<4>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact, p.split, s_tile);
+    else build_lm_rows_item<8>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact, p.split, s_tile);
+}
+
+// compact plane (spread bytes) -> the 8 response planes, for the stage entry points that hand out or read a
+// full linear memory of a refinement-only level
+__global__ __launch_bounds__(256) void k_expand_lm(const uint8_t* __restrict__ lmc, int64_t n_bytes,
+                                                   uint8_t* __restrict__ lm, int64_t lm_stride, int strip, int W, int H)
+{
+    const int64_t n4 = n_bytes >> 2; // T*T*W*H is a multiple of 16
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        int64_t src = 4 * i;
+        if (strip) { // i enumerates the row-major output: [sub][gy][gx .. gx+3]
+            const int64_t wh = (int64_t)W * H, sub = (4 * i) / wh, rem = 4 * i - sub * wh;
+            src = lm_strip_offset((int)sub, (int)(rem / W), (int)(rem % W), W, H);
+        }
+        const uint32_t v = *(const uint32_t*)(lmc + src);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) *(uint32_t*)(lm + o * lm_stride + 4 * i) = response4(v, o);
+    }
+}
+
+// unfused single-function kernels (stage entry points / parity tests)
+__global__ __launch_bounds__(256) void k_spread(const uint8_t* __restrict__ src, int rows, int cols, int T,
+                                                uint8_t* __restrict__ dst)
+{
+    const int64_t n = (int64_t)rows * cols;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+        int r = (int)(idx / cols), c = (int)(idx - (int64_t)r * cols);
+        uint8_t v = 0;
+        for (int dr = 0; dr < T && r + dr < rows; ++dr)
+            for (int dc = 0; dc < T && c + dc < cols; ++dc) v |= src[(size_t)(r + dr) * cols + c + dc];
+        dst[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_response(const uint8_t* __restrict__ spread, int64_t n,
+                                                  uint8_t* __restrict__ maps)
+{
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+        uint32_t v = spread[idx];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) maps[(int64_t)o * n + idx] = (uint8_t)response4(v, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_linearize(const uint8_t* __restrict__ map, int rows, int cols, int T,
+                                                   uint8_t* __restrict__ lm)
+{
+    const int W = cols / T, H = rows / T;
+    const int64_t n = (int64_t)rows * cols;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+        // idx enumerates the OUTPUT: [ty][tx][gy][gx]
+        int gx = (int)(idx % W);
+        int64_t t1 = idx / W;
+        int gyy = (int)(t1 % H);
+        int sub = (int)(t1 / H);
+        int ty = sub / T, tx = sub - ty * T;
+        lm[idx] = map[(size_t)(gyy * T + ty) * cols + gx * T + tx];
+    }
+}
+
+
+} // namespace sbm
