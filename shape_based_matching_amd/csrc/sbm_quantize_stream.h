@@ -92,7 +92,10 @@ struct QSState {
 // four sign tests p*|gy| - q*|gx| of the first quadrant as v_dot2_u32_u16 over (1023 - |gx|, |gy|) with the constant
 // -1023 q folded into the addend (|gx| <= 1020 < 1024, so 1023 - |gx| = |gx| ^ 1023): same 32-bit result, and the
 // unsigned form is a VOP3P instruction with a free addend (the signed one is v_dot2c: tied accumulator + v_mov)
-__device__ __forceinline__ wv::V qs_vote_word(wv::V v)
+// keep: the lanes / pixels whose vote is real (a real column AND a non-zero gradient); every other pixel votes for bin 0
+// (the ring and the columns outside the image by hysteresisGradient's border rule, a zero gradient because fastAtan2(0, 0)
+// is 0).  One select for both conditions: the predicates are combined on the scalar unit.
+__device__ __forceinline__ wv::V qs_vote_word(wv::V v, wv::P keep)
 {
     using namespace wv;
     const V av = pk_max_i16(v, pk_sub(splat(0u), v)) ^ 0x000003ffu; // (1023 - |gx|, |gy|)
@@ -100,14 +103,16 @@ __device__ __forceinline__ wv::V qs_vote_word(wv::V v)
     const V u2 = udot2(av, QS_K(264, 395), 0u - 264u * 1023u);       // 395|gy| - 264|gx| >= 0
     const V u3 = udot2(av, QS_K(395, 264), 0u - 395u * 1023u - 1u);  // 264|gy| - 395|gx| >  0
     const V u4 = udot2(av, QS_K(367, 73), 0u - 367u * 1023u - 1u);   //  73|gy| - 367|gx| >  0
-    V neg = u1 >> 31; // the four sign bits side by side
-    neg = alignbit(neg, u2, 31);
-    neg = alignbit(neg, u3, 31);
-    neg = alignbit(neg, u4, 31);
-    const V sh = splat(16u) - (popcount(neg) << 2);  // 4k, k = 0..4 boundaries passed in the first quadrant
-    const V m = ashr((v << 16) ^ v, 31);             // all ones iff exactly one of gx, gy is negative
-    const V w = 1u << (((sh ^ m) - m) & 31u);        // k -> (8 - k) & 7
-    return select(ne(v, splat(0u)), w, 1u);          // a zero gradient votes for bin 0
+    // k = number of tests that fail = boundaries NOT passed in the first quadrant: the four sign bits added up (full-rate
+    // shifts and adds; round 2 packed them with three v_alignbit and counted with v_bcnt)
+    const V k = add3(u1 >> 31, u2 >> 31, u3 >> 31) + (u4 >> 31);
+    // the vote word is 1 << 4*label with label = 4 - k, mirrored to (8 - label) & 7 when exactly one of gx, gy is
+    // negative: a ROTATE of 1 by -4*label or +4*label -- v_alignbit(1, 1, y) is 1 rotated right by y & 31, so y = 4k - 16
+    // (= -4*label) gives 1 << 4*label, and y negated gives the mirrored word; no masking, no variable shift
+    const V y = (k << 2) - 16u;
+    const V m = ashr((v << 16) ^ v, 31); // all ones iff exactly one of gx, gy is negative
+    const V w = alignbit(splat(1u), splat(1u), (y ^ m) - m);
+    return select(keep, w, 1u);
 }
 
 // One work item: strip `strip`, output rows [rb*hs, min(rb*hs+hs, rows)), frame `frame`.
@@ -462,7 +467,7 @@ __device__ __forceinline__ void quantize_stream_wave(const QSArgs& a, int strip,
                 V w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    w[j] = select(real_col[j], qs_vote_word(bv[j]), 1u);
+                    w[j] = qs_vote_word(bv[j], p_and(real_col[j], ne(bv[j], splat(0u))));
                     smc[j] = select(gt_i(bm[j], splat((uint32_t)a.thr_i)), cm[j], 0u);
                 }
                 if (a.mask) { // quantize(): angle.copyTo(dst, mask)

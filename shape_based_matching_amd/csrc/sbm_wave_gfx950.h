@@ -53,7 +53,7 @@ __device__ __forceinline__ uint32_t opaque(uint32_t k)
 
 // v_perm_b32: result byte i = selector byte i picks 0..3 -> lo.byte, 4..7 -> hi.byte, 0x0c -> 0x00
 __device__ __forceinline__ V perm(V hi, V lo, V sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-// v_alignbit_b32: ({hi, lo} >> sh) & 0xffffffff, sh in 0..31
+// v_alignbit_b32: ({hi, lo} >> (sh & 31)) & 0xffffffff; sh may be per lane (the instruction reads its low 5 bits)
 __device__ __forceinline__ V alignbit(V hi, V lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 
 // v_dot2_u32_u16 / v_dot2_i32_i16: a.lo*b.lo + a.hi*b.hi + c (32-bit wrap-around)

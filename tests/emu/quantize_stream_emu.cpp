@@ -97,3 +97,25 @@ extern "C" int sbm_emu_quantize_stream_band(const uint8_t* img, int rows, int co
     }
     return 0;
 }
+
+// the vote word (1 << 4 * label) the streaming kernel derives from a packed gradient, for n gradients: out[i] = label
+// (0..7) of (gx[i], gy[i]) -- checked exhaustively against the oracle's 16-bin rule by the CPU tests
+extern "C" void sbm_emu_vote_labels(const int16_t* gx, const int16_t* gy, int64_t n, uint8_t* out)
+{
+    for (int64_t b = 0; b < n; b += 64) {
+        wv::V v;
+        wv::P keep;
+        for (int i = 0; i < 64; ++i) {
+            const int64_t k = b + i < n ? b + i : n - 1;
+            v.l[i] = ((uint32_t)(uint16_t)gx[k]) | ((uint32_t)(uint16_t)gy[k] << 16);
+            keep.l[i] = v.l[i] != 0;
+        }
+        const wv::V w = sbm::qs_vote_word(v, keep);
+        for (int i = 0; i < 64 && b + i < n; ++i) {
+            int label = -1;
+            for (int l = 0; l < 8; ++l)
+                if (w.l[i] == (1u << (4 * l))) label = l;
+            out[b + i] = (uint8_t)label;
+        }
+    }
+}

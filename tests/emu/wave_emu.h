@@ -80,6 +80,13 @@ inline V alignbit(const V& hi, const V& lo, uint32_t sh)
     WV_FOR r.l[i] = (uint32_t)((((uint64_t)hi.l[i] << 32) | lo.l[i]) >> (sh & 31));
     return r;
 }
+// the shift amount in a VGPR: its low 5 bits, per lane
+inline V alignbit(const V& hi, const V& lo, const V& sh)
+{
+    V r;
+    WV_FOR r.l[i] = (uint32_t)((((uint64_t)hi.l[i] << 32) | lo.l[i]) >> (sh.l[i] & 31));
+    return r;
+}
 inline V udot2(const V& a, uint32_t b, const V& c)
 {
     V r;

@@ -213,3 +213,18 @@ def test_whole_groups_of_seven_rows_and_overlapping_last_block(emu, oracle, ch):
         img[rows - 20:rows - 6] = 77  # a constant band inside the rows the last two blocks both compute
         for hs in (2, 4, 8, 18, 20, 30, 32, 46, 130):
             check(emu, oracle, img, hs=hs)
+
+
+def test_vote_word_of_every_gradient(emu, oracle):
+    """the streaming kernel's vote word (four unsigned dot-product sign tests, sign bits added up, a rotate of 1) for all
+    2041 x 2041 integer gradients against the 16-bin rule of hysteresisGradient (line2Dup.cpp:225, :243-257: q & 7)"""
+    L = C.CDLL(os.path.join(EMU_DIR, "libsbm_emu.so"))
+    L.sbm_emu_vote_labels.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.sbm_emu_vote_labels.restype = None
+    r = np.arange(-1020, 1021, dtype=np.int16)
+    gx = np.ascontiguousarray(np.tile(r, len(r)))
+    gy = np.ascontiguousarray(np.repeat(r, len(r)))
+    got = np.empty(gx.size, np.uint8)
+    L.sbm_emu_vote_labels(gx.ctypes.data, gy.ctypes.data, gx.size, got.ctypes.data)
+    want = oracle.orientation_bins(gx, gy) & 7
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]

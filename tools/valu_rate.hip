@@ -59,6 +59,8 @@
 #define I_LSHLOR(n) "v_lshl_or_b32 %" #n ", %" #n ", 8, %9\n"
 #define I_BCNT(n) "v_bcnt_u32_b32 %" #n ", %" #n ", %8\n"
 #define I_FFBL(n) "v_ffbl_b32 %" #n ", %" #n "\n"
+// NOTE: selects on VCC, which the probe loop's own control flow rewrites between the instructions: this line measures that
+// dependency (22.5 cycles), not the instruction; I_CNDS (mask in an SGPR pair set once) is the issue cost: 4.06 cycles.
 #define I_CNDMASK(n) "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
 #define I_CMP(n) "v_cmp_gt_i32 vcc, %" #n ", %8\n"
 #define I_MAD24(n) "v_mad_u32_u24 %" #n ", %" #n ", %8, %9\n"
