@@ -144,10 +144,13 @@ __device__ __forceinline__ void build_lm_rows_item(const uint8_t* __restrict__ q
             if (part >= LM_FULL_SPLIT) return;
             it = item - part * base_items;
         }
-        const int64_t row_id = it / lanes_per_row; // = gy * T + ty  (a pixel row index)
+        // rows in (ty, gy) order: where a grid row has fewer than 64 lanes (W < 256: the coarsest level of a 1024^2 frame has
+        // 16), the wave's 2 - 4 rows are then CONSECUTIVE grid rows of one ty, i.e. one contiguous run of each plane
+        // (256 bytes per store instruction instead of four separate 64-byte pieces of four different planes)
+        const int64_t row_id = it / lanes_per_row;
         k = (int)(it - row_id * lanes_per_row);
         if (row_id >= rows) return;
-        r0 = (int)row_id;
+        r0 = (int)(row_id % H) * T + (int)(row_id / H); // pixel row gy * T + ty
     }
     const int gy = r0 / T, ty = r0 - gy * T;
     const int c0 = k * 4 * T; // first pixel column of this lane
