@@ -696,6 +696,7 @@ def main():
             "matches_distinct": n_matches,
             "coarse_candidates_rank0": n_cand,
         }
+        frac_by_frame = {}
         if strong:
             cfg["strong_estimate"] = strong
         if extra:
@@ -710,6 +711,13 @@ def main():
             cfg["textured_us_per_frame"] = extra["textured"]["us_per_frame"]
             cfg["stage_a_us_per_frame"] = extra["stage_a"]["us_per_frame"]
             cfg["other_frames"] = extra
+            # the dominant kernel's fraction of the HBM roofline on those frames (same algorithmic bytes, that frame's launch
+            # times): round 2's headline frame was the case1 canvas
+            frac_by_frame = {}
+            for key, e in extra.items():
+                t = e["kernel_launch_us"].get(dom)
+                if t:
+                    frac_by_frame[key] = dom_bytes / (sum(t) / len(t) * 1e-6) / 1e9 / HBM_PEAK_GBS
         out = {
             "metric": "templates*Mpixels/sec (whole Detector::match, frame resident in HBM)" if wl.stage == "match"
                       else "templates*Mpixels/sec (template loop only, pyramid resident)",
@@ -736,6 +744,7 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": dom_bytes,
                 "avg_launch_us": kern[dom]["avg_launch_us"],
+                "frac_on_other_frames": frac_by_frame if extra else None,
                 "note": "per launch = the frames of one step; figures are the mean over this kernel's launches of a step "
                         "(k_quantize: one launch per pyramid level).  `bound` names the roofline the fraction is taken against "
                         "(HBM, as BASELINE's north_star asks); `limiter` is what the counters say actually bounds the kernel",
