@@ -255,7 +255,9 @@ def main():
     if args.warmup is None:
         args.warmup = max(2, args.steps // 10)
     if args.inflight <= 0:
-        args.inflight = 3 if args.config == "case1" else 2
+        # c4: one coarse launch (26 ms for 4 500 templates) fills the GPU for its whole length; a second one in flight only
+        # contends with it (32.5 ms per step with two slots against 26.2 with one)
+        args.inflight = {"case1": 3, "c4": 1}.get(args.config, 2)
     # More than 3 slots is not a win on a stock runtime: HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware
     # queues (default 4) and two streams that share a queue run their kernels in order -- 4 slots + the null stream
     # measure 14.5 us per frame, 7.4 with GPU_MAX_HW_QUEUES=8.
