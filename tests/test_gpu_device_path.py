@@ -602,3 +602,45 @@ def test_strip_plane_refinement_with_clamped_patches(oracle, ctx_factory, case1,
             assert cnt[f, 1] == 0 and cnt[f, 0] == len(want), (f, cnt[f].tolist(), len(want))
             assert key(out[f].view(MATCH_DTYPE)[: cnt[f, 0]]) == key(want)
         assert len(want) >= 90  # thresholds <= 0 and 10: every coarse position of the (small) span is a candidate
+
+
+def test_pipeline_depth_hint_changes_launch_sizes_not_results(oracle, ctx_factory, case1):
+    """sbm_set_pipeline_depth(3): the gradient launches take fewer, longer work items (32 rows) and the refinement pass 128
+    candidate slots per frame; maps, linear memories and match lists are those of the default sizing.  Frame heights that
+    are and are not multiples of 32 (the last row block is moved up), a 16-frame batch as in bench.py."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    ts = case1["templates"].subset(range(300, 361, 3))
+    stream = torch.cuda.Stream(device=dev)
+    cap, rec = 512, MATCH_DTYPE.itemsize
+    for rows, cols, B in ((640, 768, 16), (656, 1024, 5)):
+        base = synth.embed(case1["test"], rows, cols, 80, 80)
+        frames = np.stack([np.roll(base, 8 * b, axis=1) for b in range(B)])
+        frames[B // 2] = synth.scene_with_object(9, rows, cols, case1["test"])
+        d_imgs = torch.from_numpy(frames).to(dev)
+        results = []
+        for depth in (1, 3):
+            ctx = ctx_factory()
+            ctx.upload_templates(ts)
+            ctx.set_quantize_mode("stream")
+            ctx.set_pipeline_depth(depth)
+            d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)
+            d_cnt = torch.zeros(B * 2, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            ctx.match_batch_device(d_imgs.data_ptr(), rows * cols * 3, B, rows, cols, cols * 3, 3, 85.0, d_out.data_ptr(), cap, d_cnt.data_ptr(),
+                                   stream=stream.cuda_stream)
+            stream.synchronize()
+            cnt = d_cnt.cpu().numpy().reshape(B, 2)
+            out = d_out.cpu().numpy().reshape(B, cap * rec)
+            results.append(([key(out[f].view(MATCH_DTYPE)[: cnt[f, 0]]) for f in range(B)], ctx.get_quantized(0), ctx.get_quantized(1),
+                            ctx.get_linear_memories(1)))
+        p = oracle.Pyramid.build(frames[0], [4, 8], 30.0)
+        assert np.array_equal(results[1][1], p.quantized(0)) and np.array_equal(results[1][2], p.quantized(1))
+        assert np.array_equal(results[1][3], p.lm(1))
+        p.free()
+        assert results[0][0] == results[1][0] and sum(len(x) for x in results[1][0]) > 0
+        for f in (B // 2, B - 1):
+            p = oracle.Pyramid.build(frames[f], [4, 8], 30.0)
+            assert results[1][0][f] == key(p.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 85.0)), f
+            p.free()
