@@ -62,19 +62,43 @@ def run(n_cases, seed, verbose=True):
         ctx = capi.Context(T=(4, 8), weak_threshold=30.0, device_id=0)
         ctx.upload_templates(ts)
         ctx.set_quantize_mode(qmode, hs)
+        depth = int(rs.choice([1, 3]))  # round 3: throughput sizing of the launches (identical results)
+        ctx.set_pipeline_depth(depth)
+        # round 3: the entry point is drawn too -- the device batch, the pipelined host batch (sub-batches of 1..4), or the
+        # build-sharded step run on one GPU (every row band launched here); bands need rows_l % n == 0 with an even quotient
+        entry = str(rs.choice(["device", "host", "banded"]))
+        n_bands = 0
+        if entry == "banded":
+            ok = [n for n in (2, 3, 4, 5, 6, 8) if (rows // 2) % n == 0 and ((rows // 2) // n) % 2 == 0 and rows % n == 0 and (rows // n) % 2 == 0]
+            if qmode == "tile" or not ok:
+                entry = "device"
+            else:
+                n_bands = int(rs.choice(ok))
         cap, rec = 8192, MATCH_DTYPE.itemsize
         stream = torch.cuda.Stream(device=dev)
-        d_img = torch.from_numpy(np.stack(frames)).to(dev)
-        d_mask = torch.from_numpy(mask).to(dev) if mask is not None else None
-        d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)
-        d_cnt = torch.zeros(B * 2, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
-        ctx.match_batch_device(d_img.data_ptr(), frames[0].size, B, rows, cols, cols * ch, ch, thr, d_out.data_ptr(), cap, d_cnt.data_ptr(),
-                               d_mask=d_mask.data_ptr() if d_mask is not None else 0, stream=stream.cuda_stream)
-        stream.synchronize()
-        cnt = d_cnt.cpu().numpy().reshape(B, 2)
-        out = d_out.cpu().numpy().reshape(B, cap * rec)
-        desc = (case, rows, cols, ch, B, n_t, thr, kind, mask is not None, os.environ["SBM_COARSE"], qmode, hs)
+        if entry == "host":
+            lists = ctx.match_batch_host(frames, thr, cap=cap, sub_batch=int(rs.randint(1, 5)), mask=mask, split=bool(rs.randint(0, 2)))
+            cnt = np.array([[len(l), 0] for l in lists], np.int32)
+            out = np.zeros((B, cap * rec), np.uint8)
+            for f, l in enumerate(lists):
+                out[f, : len(l) * rec] = np.ascontiguousarray(l).view(np.uint8)
+        else:
+            d_img = torch.from_numpy(np.stack(frames)).to(dev)
+            d_mask = torch.from_numpy(mask).to(dev) if mask is not None else None
+            hdr = (8 * B + 15) // 16 * 16
+            d_buf = torch.zeros(hdr + B * cap * rec, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            if entry == "banded":
+                ctx.match_batch_device_banded(d_img.data_ptr(), frames[0].size, B, rows, cols, cols * ch, ch, thr, d_buf.data_ptr(), cap,
+                                              n_bands=n_bands, stream=stream.cuda_stream, d_mask=d_mask.data_ptr() if d_mask is not None else 0)
+            else:
+                ctx.match_batch_device(d_img.data_ptr(), frames[0].size, B, rows, cols, cols * ch, ch, thr, d_buf.data_ptr() + hdr, cap,
+                                       d_buf.data_ptr(), d_mask=d_mask.data_ptr() if d_mask is not None else 0, stream=stream.cuda_stream)
+            stream.synchronize()
+            h = d_buf.cpu().numpy()
+            cnt = h[: 8 * B].view(np.int32).reshape(B, 2)
+            out = h[hdr:].reshape(B, cap * rec)
+        desc = (case, rows, cols, ch, B, n_t, thr, kind, mask is not None, os.environ["SBM_COARSE"], qmode, hs, depth, entry, n_bands)
         for f in range(B):
             pyr = O.Pyramid.build(frames[f], [4, 8], 30.0, mask=mask)
             want = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr, n_threads=min(16, os.cpu_count() or 1))
