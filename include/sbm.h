@@ -113,7 +113,8 @@ int sbm_match_sharded(sbm_ctx* const* ctxs, int32_t n_ctx, const uint8_t* img_ho
  * pinned host block written by the last kernel.  frames[f] points to frame f (rows x stride bytes).  Results: the
  * records of frame f at out + f * cap, {n_matches, overflow} at counts + 2 * f.  _begin enqueues everything and
  * returns (uploads from memory that is not pinned are staged by the runtime and may block meanwhile); _end waits and
- * copies the lists out; one batch in flight per context.  SBM_ERR_CAPACITY if a frame has more than cap matches (its
+ * copies the lists out; one batch in flight per context.  The frames and the mask must stay mapped and unchanged
+ * from _begin until _end has returned (pinned memory is read by the copy engine during that time).  SBM_ERR_CAPACITY if a frame has more than cap matches (its
  * first cap records are still returned). */
 int sbm_match_batch_host_begin(sbm_ctx* ctx, const uint8_t* const* frames, int32_t n_frames, int32_t rows, int32_t cols,
                                int32_t stride, int32_t channels, const uint8_t* mask_host, float threshold, int64_t cap,
