@@ -175,6 +175,12 @@ int sbm_set_graph_mode(sbm_ctx* ctx, int32_t enabled);
  * bit-identical either way; this is a tuning / test knob. */
 int sbm_set_quantize_mode(sbm_ctx* ctx, int32_t mode, int32_t rows_per_wave);
 
+/* Which coarse-pass kernel (similarity / similarity_64 + candidate scan, line2Dup.cpp:807-858, :924-984, :1199-1216) the
+ * match entry points launch.  0 (default): by launch size -- one wave per (1024 positions, template, frame) for batches
+ * and large template sets, four waves sharing an item's features for a single frame with a few hundred templates;
+ * 1: always the four-wave kernel; 2: always the one-wave kernel.  Identical candidates either way; a test / tuning knob. */
+int sbm_set_coarse_mode(sbm_ctx* ctx, int32_t mode);
+
 /* Hint: how many batches the caller keeps in flight on this GPU at the same time (through other contexts and
  * streams; bench.py runs three).  1 (default): every launch is sized for its own latency -- all its work items resident
  * at once.  >= 2: launches are sized for throughput -- the row-streaming gradient kernel takes fewer, longer work items

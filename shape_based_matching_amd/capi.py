@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "sbm_match_batch_device_banded", "sbm_pin_host_buffer", "sbm_unpin_host_buffer",
     "sbm_select_templates", "sbm_partition_templates", "sbm_match_sharded",
     "sbm_match_batch_host", "sbm_match_batch_host_begin", "sbm_match_batch_host_end", "sbm_extract_local_maxima",
-    "sbm_set_pipeline_depth",
+    "sbm_set_pipeline_depth", "sbm_set_coarse_mode",
 ]
 
 
@@ -143,6 +143,7 @@ def lib() -> C.CDLL:
     L.sbm_match_batch_device_sharded.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp, vp]
     L.sbm_extract_local_maxima.argtypes = [vp, vp, vp, i32, i32, f32, vp, i64, C.POINTER(i64)]
     L.sbm_set_pipeline_depth.argtypes = [vp, i32]
+    L.sbm_set_coarse_mode.argtypes = [vp, i32]
     L.sbm_select_templates.argtypes = [vp, vp, i32]
     L.sbm_partition_templates.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp]
     L.sbm_match_sharded.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, f32, vp, i64, C.POINTER(i64)]
@@ -368,6 +369,10 @@ class Context:
     def set_quantize_mode(self, mode: str = "auto", rows_per_wave: int = 0):
         """gradient kernel choice: "auto" (by launch size), "tile" or "stream"; bit-identical results"""
         _check(lib().sbm_set_quantize_mode(self._h, {"auto": 0, "tile": 1, "stream": 2}[mode], rows_per_wave))
+
+    def set_coarse_mode(self, mode: str = "auto"):
+        """coarse-pass kernel: "auto" (by launch size), "block" (four waves per item) or "wave"; identical candidates"""
+        _check(lib().sbm_set_coarse_mode(self._h, {"auto": 0, "": 0, "block": 1, "wave": 2}[mode]))
 
     def set_pipeline_depth(self, batches_in_flight: int):
         """hint: the caller keeps this many batches in flight on the GPU -> launches are sized for throughput (>= 2)"""

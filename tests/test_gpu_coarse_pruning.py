@@ -3,7 +3,7 @@
 The coarse pass (similarity, line2Dup.cpp:807-858 / :924-984, scanned at :1199-1216) stops an item after a prefix of
 its features when no position can reach the threshold any more.  Nothing that could have reached the threshold may be
 dropped: over a range of thresholds -- which moves the prefix from "no pruning" (low thresholds) to 8 features -- and
-with either kernel forced (SBM_COARSE, read when a context is created), the match lists must equal the oracle's."""
+with either kernel forced (sbm_set_coarse_mode), the match lists must equal the oracle's."""
 import os
 
 import numpy as np
@@ -22,21 +22,16 @@ def multiset(recs):
 @pytest.fixture()
 def forced_ctx():
     made = []
-    saved = os.environ.get("SBM_COARSE")
 
     def make(mode, **kw):
-        os.environ["SBM_COARSE"] = mode
         c = capi.Context(T=kw.pop("T", (4, 8)), weak_threshold=30.0, device_id=0, max_candidates=kw.pop("max_candidates", 0))
+        c.set_coarse_mode(mode)
         made.append(c)
         return c
 
     yield make
     for c in made:
         c.close()
-    if saved is None:
-        os.environ.pop("SBM_COARSE", None)
-    else:
-        os.environ["SBM_COARSE"] = saved
 
 
 @pytest.mark.parametrize("mode", ["block", "wave"])

@@ -25,8 +25,8 @@ d_out = torch.zeros(B * cap * MATCH_DTYPE.itemsize, dtype=torch.uint8, device="c
 d_cnt = torch.zeros(B * 2, dtype=torch.int32, device="cuda")
 s = torch.cuda.Stream()
 for mode in ("wave", "block"):
-    os.environ["SBM_COARSE"] = mode
     ctx = capi.Context(T=(4, 8), weak_threshold=30.0, device_id=0)
+    ctx.set_coarse_mode(mode)
     ctx.upload_templates(ts)
     for thr in (60.0, 80.0, 85.0, 90.0, 95.0, 99.0, 100.0):
         def run():

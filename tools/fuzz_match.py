@@ -56,12 +56,13 @@ def run(n_cases, seed, verbose=True):
         if rs.randint(0, 4) == 0:
             mask = np.zeros((rows, cols), np.uint8)
             mask[rows // 8: rows - rows // 6, cols // 7: cols - cols // 9] = 255
-        os.environ["SBM_COARSE"] = str(rs.choice(["", "block", "wave"]))
+        cmode = str(rs.choice(["", "block", "wave"]))
         qmode = str(rs.choice(["auto", "tile", "stream"]))
         hs = int(rs.choice([0, 6, 8, 16, 28]))
         ctx = capi.Context(T=(4, 8), weak_threshold=30.0, device_id=0)
         ctx.upload_templates(ts)
         ctx.set_quantize_mode(qmode, hs)
+        ctx.set_coarse_mode(cmode)
         depth = int(rs.choice([1, 3]))  # round 3: throughput sizing of the launches (identical results)
         ctx.set_pipeline_depth(depth)
         # round 3: the entry point is drawn too -- the device batch, the pipelined host batch (sub-batches of 1..4), or the
@@ -98,7 +99,7 @@ def run(n_cases, seed, verbose=True):
             h = d_buf.cpu().numpy()
             cnt = h[: 8 * B].view(np.int32).reshape(B, 2)
             out = h[hdr:].reshape(B, cap * rec)
-        desc = (case, rows, cols, ch, B, n_t, thr, kind, mask is not None, os.environ["SBM_COARSE"], qmode, hs, depth, entry, n_bands)
+        desc = (case, rows, cols, ch, B, n_t, thr, kind, mask is not None, cmode, qmode, hs, depth, entry, n_bands)
         for f in range(B):
             pyr = O.Pyramid.build(frames[f], [4, 8], 30.0, mask=mask)
             want = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr, n_threads=min(16, os.cpu_count() or 1))
