@@ -618,7 +618,7 @@ def main():
         for kind, key in (("case1", "case1_canvas"), ("tiled", "textured"), ("stagea", "stage_a")):
             fr = case1_frame(kind, ROWS, COLS)
             d_img.copy_(torch.from_numpy(np.stack([np.roll(fr, 8 * b, axis=1) for b in range(B)])).to(dev))
-            n = max(20, min(args.steps, 300))
+            n = max(100, min(args.steps, 300))  # secondary figures: at least 100 steps whatever --steps says
             el = timed(max(5, n // 10), n)
             k2 = kernel_pass(min(n, 30))
             fence()
