@@ -181,6 +181,13 @@ int sbm_set_quantize_mode(sbm_ctx* ctx, int32_t mode, int32_t rows_per_wave);
  * 1: always the four-wave kernel; 2: always the one-wave kernel.  Identical candidates either way; a test / tuning knob. */
 int sbm_set_coarse_mode(sbm_ctx* ctx, int32_t mode);
 
+/* Which candidate a workgroup of the refinement pass (similarityLocal(_64) + the loop at line2Dup.cpp:1221-1293) takes.
+ * 0: a grid of (frames x slots), every frame's candidates walked by that frame's slots; 2: the candidates of up to 64
+ * frames as ONE frame-major list walked by the whole grid (the workgroups running together stay on one or two frames,
+ * whose linear memories then stay in the L2s); -1 (default): 2 once the batch's finest-level planes exceed the L2s
+ * together (32 MiB), else 0.  Identical matches either way; a test / tuning knob. */
+int sbm_set_refine_order(sbm_ctx* ctx, int32_t order);
+
 /* Hint: how many batches the caller keeps in flight on this GPU at the same time (through other contexts and
  * streams; bench.py runs three).  1 (default): every launch is sized for its own latency -- all its work items resident
  * at once.  >= 2: launches are sized for throughput -- the row-streaming gradient kernel takes fewer, longer work items

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "sbm_match_batch_device_banded", "sbm_pin_host_buffer", "sbm_unpin_host_buffer",
     "sbm_select_templates", "sbm_partition_templates", "sbm_match_sharded",
     "sbm_match_batch_host", "sbm_match_batch_host_begin", "sbm_match_batch_host_end", "sbm_extract_local_maxima",
-    "sbm_set_pipeline_depth", "sbm_set_coarse_mode",
+    "sbm_set_pipeline_depth", "sbm_set_coarse_mode", "sbm_set_refine_order",
 ]
 
 
@@ -144,6 +144,7 @@ def lib() -> C.CDLL:
     L.sbm_extract_local_maxima.argtypes = [vp, vp, vp, i32, i32, f32, vp, i64, C.POINTER(i64)]
     L.sbm_set_pipeline_depth.argtypes = [vp, i32]
     L.sbm_set_coarse_mode.argtypes = [vp, i32]
+    L.sbm_set_refine_order.argtypes = [vp, i32]
     L.sbm_select_templates.argtypes = [vp, vp, i32]
     L.sbm_partition_templates.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp]
     L.sbm_match_sharded.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, f32, vp, i64, C.POINTER(i64)]
@@ -373,6 +374,10 @@ class Context:
     def set_coarse_mode(self, mode: str = "auto"):
         """coarse-pass kernel: "auto" (by launch size), "block" (four waves per item) or "wave"; identical candidates"""
         _check(lib().sbm_set_coarse_mode(self._h, {"auto": 0, "": 0, "block": 1, "wave": 2}[mode]))
+
+    def set_refine_order(self, order: str = "auto"):
+        """refinement pass: "auto" (by the batch's plane size), "slots" (per-frame slots) or "list" (one frame-major list)"""
+        _check(lib().sbm_set_refine_order(self._h, {"auto": -1, "slots": 0, "list": 2}[order]))
 
     def set_pipeline_depth(self, batches_in_flight: int):
         """hint: the caller keeps this many batches in flight on the GPU -> launches are sized for throughput (>= 2)"""

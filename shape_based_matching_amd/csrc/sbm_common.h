@@ -45,6 +45,15 @@ __device__ __forceinline__ void cand_fill_next(Cand& c, const DevTL* __restrict_
     c.pad = 0;
 }
 
+// Per-frame counters of the template loop, three 128-byte lines per frame.  The candidate count is READ by every
+// workgroup of the refinement pass while other workgroups arrive: arrivals are device-scope atomics, performed at the
+// memory side, and a load of a line they are hitting waits behind them -- so the count, the arrival levels and the
+// sub-arrivals each have a line of their own.
+constexpr int CTR_STRIDE = 96;  // int32 per frame
+constexpr int CTR_COUNT = 0;    // candidates of the coarse pass ([2,3]: refinement bytes, sbm_get_stats)
+constexpr int CTR_ARRIVE = 32;  // [32] arrivals of sub-counters, [33] arrivals of frames (k_similarity_local groups)
+constexpr int CTR_SUB = 64;     // [64..95] arrivals of workgroups
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int reflect101(int p, int len)
 {

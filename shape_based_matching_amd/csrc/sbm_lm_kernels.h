@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_build_lm_rows(const LmArgs a)
     __shared__ uint32_t s_tile[8 * 256]; // strip levels: the workgroup's spread dwords, [tx][strip][row][4 cells]
     const size_t frame = blockIdx.y; // batch of frames: one grid row each
     if (blockIdx.x == 0 && a.counters) {
-        if (threadIdx.x < 40) a.counters[frame * 40 + threadIdx.x] = 0;
+        if (threadIdx.x < CTR_STRIDE) a.counters[frame * CTR_STRIDE + threadIdx.x] = 0;
         if (threadIdx.x < 2 && a.out_count) a.out_count[frame * 2 + threadIdx.x] = 0;
     }
     // the level whose block range holds this block (the host orders the ranges heaviest blocks first)

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void k_copy_bytes(const uint8_t* __restrict__ 
 // zero the per-call counters (one launch instead of two memsets)
 __global__ void k_reset(int32_t* __restrict__ counters, int32_t* __restrict__ out_count)
 {
-    if (threadIdx.x < 40) counters[threadIdx.x] = 0; // [0] candidates [2,3] refine bytes [4] arrivals [8..39] sub-arrivals
+    for (int i = threadIdx.x; i < CTR_STRIDE; i += blockDim.x) counters[i] = 0; // layout: sbm_common.h CTR_*
     if (threadIdx.x < 2) out_count[threadIdx.x] = 0;
 }
 
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void k_similarity_coarse(
     coarse_block_item(chunk_id, templ_slot, frame);
     lm += (size_t)frame * lm_fs;
     cands += (size_t)frame * cap;
-    counters += (size_t)frame * 40;
+    counters += (size_t)frame * CTR_STRIDE;
     const int t = active[templ_slot];
     const DevTL tl = tls[(size_t)t * L + lc];
     const int npos = template_positions(tl, W, H, T);
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void k_similarity_coarse_wave(
     const CoarseItem it = items[templ_slot];
     lm += (size_t)frame * lm_fs;
     cands += (size_t)frame * cap;
-    counters += (size_t)frame * 40;
+    counters += (size_t)frame * CTR_STRIDE;
     const int t = it.t;
     const int npos = it.npos;
     const int rmin = it.rmin;
@@ -635,6 +635,38 @@ __global__ __launch_bounds__(256) void k_similarity_map(const uint8_t* __restric
     }
 }
 
+// Arrival of the working workgroups of one group of `nfr` frames (k_similarity_local); true in EVERY thread of the one
+// workgroup that arrives last -- or of workgroup 0 when nobody works.  Idle workgroups do not arrive (they must not
+// queue up behind the working ones).  Arrivals on one 128-byte line serialise at ~25 ns each whatever the address inside
+// it, so the arrivals are spread over the lines of the group's frames (counters + CTR_STRIDE f) in three levels:
+//   workgroup b -> sub-counter (frame fs = b % nfr, sub = (b / nfr) % 32)   [CTR_SUB + sub] of frame fs
+//   last of a sub-counter -> frame fs                                        [CTR_ARRIVE] of frame fs   (<= 32 arrivals)
+//   last of a frame -> the group                                             [CTR_ARRIVE + 1] of frame 0 (<= nfr arrivals)
+// No fence: the publishing workgroup only reads out_count (device-scope atomics); the records themselves become
+// visible to the host and to later kernels at the end of the kernel.
+__device__ __forceinline__ bool arrive_last(int32_t* __restrict__ counters, int nfr, int n_work, bool worked, int b)
+{
+    if (!worked && !(n_work == 0 && b == 0)) return false; // block-uniform
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool last = n_work == 0;
+        if (!last) {
+            const int S = nfr * 32, s = b % S, fs = s % nfr, sub = s / nfr;
+            const int expect = (n_work - s + S - 1) / S;                 // working blocks on this sub-counter
+            const int used = n_work < S ? n_work : S;                    // sub-counters in use
+            const int subs_of_frame = (used - fs + nfr - 1) / nfr;       // ... of them on frame fs
+            const int frames_used = n_work < nfr ? n_work : nfr;
+            int32_t* cf = counters + (size_t)fs * CTR_STRIDE;
+            if (atomicAdd(&cf[CTR_SUB + sub], 1) == expect - 1)
+                if (atomicAdd(&cf[CTR_ARRIVE], 1) == subs_of_frame - 1) last = atomicAdd(&counters[CTR_ARRIVE + 1], 1) == frames_used - 1;
+        }
+        s_last = last ? 1 : 0;
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
 // End of the emitting kernel: the last WORKING block to finish (arrival counter counters[4]) writes the
 // overflow status and mirrors the final {count, overflow} pair to the caller's mirror (plain stores:
 // it may be pinned host memory).  Only blocks that had a candidate arrive — atomics on one address
@@ -656,7 +688,7 @@ __device__ __forceinline__ void publish_counts(int32_t* __restrict__ counters, i
             const int groups = n_work_blocks < 32 ? n_work_blocks : 32;
             // no fence: the last block only reads out_count (device-scope atomics); the records themselves
             // become visible to the host and to later kernels at the end of the kernel
-            if (atomicAdd(&counters[8 + sub], 1) == expect - 1) last = atomicAdd(&counters[4], 1) == groups - 1;
+            if (atomicAdd(&counters[CTR_SUB + sub], 1) == expect - 1) last = atomicAdd(&counters[CTR_ARRIVE], 1) == groups - 1;
         }
         if (last) {
             const int n_out = atomicAdd(out_count, 0);
@@ -869,7 +901,19 @@ __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int6
     __syncthreads();
 }
 
-template <int COMPACT, int LW>
+// ORDER: which candidate a workgroup takes.
+//   0  grid = (frames, slots): workgroup (f, s) takes candidates s, s + slots, ... of frame f; the frame is the FAST
+//      grid dimension, so the workgroups dispatched first are the low slots of every frame -- the ones that have a
+//      candidate -- and the idle slots come last.  Best while the batch's strip planes fit the L2s.
+//   2  grid = (workgroups, groups of up to 64 frames): the candidates of a group's frames form ONE list in frame-major
+//      order and workgroup b takes entries b, b + gridDim.x, ...: the workgroups running at any moment are on one or
+//      two frames, whose strip planes then stay in the L2s (with order 0 a 64-frame 1080p batch has 64 planes in
+//      flight: 128 MiB against 8 x 4 MiB of L2), and the grid is as full as the batch's candidate count, not as each
+//      frame's.  Costs a running sum of the frames' counts per wave before the first candidate record can be fetched
+//      and a third arrival level: config 5 (64 frames, ~1400 candidates each) 1878 -> 1753 us per step, but 16 tiled
+//      1024^2 frames 200 -> 207 us (tools/r03_local_order.sh), so the host picks by the planes' total size.
+//   (the frame as the SLOW dimension of order 0's grid was measured too: between the two on config 5, 1825 us)
+template <int COMPACT, int LW, int ORDER>
 __global__ __launch_bounds__(64 * LW) void k_similarity_local(
     const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int l,
     const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
@@ -877,31 +921,50 @@ __global__ __launch_bounds__(64 * LW) void k_similarity_local(
     const int32_t* __restrict__ template_id, Cand* __restrict__ cands, int32_t* __restrict__ counters,
     int cand_cap, int is_last, sbm_match_rec* __restrict__ out, int32_t* __restrict__ out_count,
     int out_cap, sbm_match_rec* __restrict__ mirror_out, int32_t* __restrict__ mirror_count, int collect_stats,
-    int64_t lm_fs, const uint8_t* __restrict__ flabel, const uint16_t* __restrict__ fcls)
+    int64_t lm_fs, const uint8_t* __restrict__ flabel, const uint16_t* __restrict__ fcls, int frames)
 {
-    // grid = (frames, candidate slots): the frame is the FAST grid dimension, so the blocks dispatched first are
-    // the low slots of every frame -- the ones that have a candidate -- and the idle slots come last
-    const int slot = blockIdx.y, n_slots = gridDim.y;
-    {
-        const size_t frame = blockIdx.x;
-        lm += frame * lm_fs;
-        cands += frame * cand_cap;
-        counters += frame * 40;
-        out += frame * out_cap;
-        out_count += frame * 2;
-        if (mirror_out) mirror_out += frame * out_cap;
-        if (mirror_count) mirror_count += frame * 2;
-    }
-    __shared__ uint32_t s_part[LW][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // the candidate count and this block's first candidate are fetched together (the record is read
-    // speculatively: the buffer always exists, the count decides whether it is used)
-    Cand c = cands[slot < cand_cap ? slot : 0];
-    const int n_all = counters[0];
-    const int n = n_all < cand_cap ? n_all : cand_cap;
+    // ORDER 2: lane = frame of the group: candidate counts, their running sums, and from those (frame, index) of entry g
+    const int f_first = ORDER == 2 ? (int)blockIdx.y * 64 : 0;
+    const int nfr = frames - f_first < 64 ? frames - f_first : 64;
+    int n_all_l = 0, incl = 0, excl = 0;
+    // ORDER 0: one frame per workgroup; the candidate count and the workgroup's first candidate are fetched together
+    // (the record is read speculatively: the buffer always exists, the count decides whether it is used)
+    const int slot = ORDER == 0 ? blockIdx.y : blockIdx.x, n_slots = ORDER == 0 ? gridDim.y : gridDim.x;
+    const size_t frame_wg = ORDER == 0 ? blockIdx.x : 0;
+    Cand c_first;
+    int tot, n_all_wg = 0;
+    if (ORDER == 2) {
+        if (lane < nfr) n_all_l = counters[(size_t)(f_first + lane) * CTR_STRIDE];
+        const int n_l = n_all_l < cand_cap ? n_all_l : cand_cap;
+        incl = n_l;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            incl += lane >= d ? o : 0;
+        }
+        excl = incl - n_l;
+        tot = __builtin_amdgcn_readlane(incl, 63);
+    } else {
+        c_first = cands[frame_wg * cand_cap + (slot < cand_cap ? slot : 0)];
+        n_all_wg = counters[frame_wg * CTR_STRIDE];
+        tot = n_all_wg < cand_cap ? n_all_wg : cand_cap;
+    }
+    const int g_first = ORDER == 2 ? (int)blockIdx.x : slot, g_step = ORDER == 2 ? (int)gridDim.x : n_slots;
+    __shared__ uint32_t s_part[LW][2][64];
     const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
-    for (int ci = slot; ci < n; ci += n_slots) {
-        if (ci != slot) c = cands[ci];
+    unsigned long long stat_bytes = 0;
+    for (int g = g_first; g < tot; g += g_step) {
+        size_t frame = frame_wg;
+        int ci = g;
+        if (ORDER == 2) {
+            // first frame whose running sum passes g (g < tot: there is one); wave-uniform, and said so to the compiler
+            const int fl = __builtin_amdgcn_readfirstlane(__builtin_ctzll(__ballot(g < incl)));
+            ci = __builtin_amdgcn_readfirstlane(g - __builtin_amdgcn_readlane(excl, fl));
+            frame = (size_t)(f_first + fl);
+        }
+        Cand* const cand_p = cands + frame * cand_cap + ci;
+        Cand c = ORDER != 2 && g == g_first ? c_first : *cand_p;
         if (c.raw < 0) continue; // dropped at a coarser level (uniform per block)
         DevTL tl;
         tl.width = c.next_width;
@@ -916,7 +979,7 @@ __global__ __launch_bounds__(64 * LW) void k_similarity_local(
         y = y > max_y ? max_y : y;
         const int ox = (x / T - 8) * T, oy = (y / T - 8) * T;
         uint32_t lo, hi;
-        local_patch<COMPACT, LW>(lm, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi, flabel,
+        local_patch<COMPACT, LW>(lm + frame * lm_fs, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi, flabel,
                                  COMPACT == 2 ? fcls + ((size_t)c.t * L + l) * 17 : nullptr);
         if (wave != 0) continue;
         // first maximum in row-major order, strict '>' from 0 (:1265-1282): maximise (raw, -position)
@@ -934,7 +997,7 @@ __global__ __launch_bounds__(64 * LW) void k_similarity_local(
             best = o > best ? o : best;
         }
         if (lane == 0) {
-            if (collect_stats) atomicAdd((unsigned long long*)(counters + 2), (unsigned long long)tl.nf * 256ull); // refinement bytes
+            if (frame == 0) stat_bytes += (unsigned long long)tl.nf * 256ull; // refinement bytes (sbm_get_stats: frame 0)
             const int raw = (int)(best >> 8);
             int br = -1, bc = -1;
             if (raw > 0) {
@@ -947,7 +1010,7 @@ __global__ __launch_bounds__(64 * LW) void k_similarity_local(
             const bool keep = raw >= c.next_keep;
             if (is_last) {
                 if (keep) {
-                    int idx = atomicAdd(out_count, 1);
+                    int idx = atomicAdd(out_count + frame * 2, 1);
                     if (idx < out_cap) {
                         sbm_match_rec m;
                         m.x = nx;
@@ -956,8 +1019,8 @@ __global__ __launch_bounds__(64 * LW) void k_similarity_local(
                         m.raw = raw;
                         m.class_idx = c.class_idx;
                         m.template_id = c.template_id;
-                        out[idx] = m;
-                        if (mirror_out) mirror_out[idx] = m; // e.g. pinned host memory: no copy engine involved
+                        out[frame * out_cap + idx] = m;
+                        if (mirror_out) mirror_out[frame * out_cap + idx] = m; // e.g. pinned host memory: no copy engine involved
                     }
                 }
             } else {
@@ -965,13 +1028,31 @@ __global__ __launch_bounds__(64 * LW) void k_similarity_local(
                 c.y = ny;
                 c.raw = keep ? raw : -1;
                 if (keep) cand_fill_next(c, tls, raw_keep, class_idx, template_id, L, l - 1);
-                cands[ci] = c;
+                *cand_p = c;
             }
         }
     }
-    if (is_last) {
-        const int n_work = n < n_slots ? n : n_slots;
-        publish_counts(counters, n_all, n_work, slot < n, cand_cap, out_count, mirror_count, slot);
+    // one addition per workgroup, not per candidate (a per-candidate atomic on one address stretched the very launch
+    // it was measuring)
+    if (collect_stats && threadIdx.x == 0 && stat_bytes) atomicAdd((unsigned long long*)(counters + 2), stat_bytes);
+    if (is_last && ORDER == 2) {
+        // the last working workgroup of the group publishes every frame's count
+        const int n_work = tot < (int)gridDim.x ? tot : (int)gridDim.x;
+        const bool last = arrive_last(counters + (size_t)f_first * CTR_STRIDE, nfr, n_work, (int)blockIdx.x < n_work, (int)blockIdx.x);
+        if (last && wave == 0 && lane < nfr) {
+            const size_t frame = (size_t)(f_first + lane);
+            const int n_out = atomicAdd(out_count + frame * 2, 0);
+            const int flag = n_all_l > cand_cap ? 1 : 0;
+            out_count[frame * 2 + 1] = flag;
+            if (mirror_count) {
+                mirror_count[frame * 2] = n_out;
+                mirror_count[frame * 2 + 1] = flag;
+            }
+        }
+    } else if (is_last) {
+        const int n_work = tot < n_slots ? tot : n_slots;
+        publish_counts(counters + frame_wg * CTR_STRIDE, n_all_wg, n_work, slot < tot, cand_cap, out_count + frame_wg * 2,
+                       mirror_count ? mirror_count + frame_wg * 2 : nullptr, slot);
     }
 }
 
@@ -1006,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_emit_coarse(const Cand* __restrict__ ca
     { // batch of frames: frame = blockIdx.y
         const size_t frame = blockIdx.y;
         cands += frame * cand_cap;
-        counters += frame * 40;
+        counters += frame * CTR_STRIDE;
         out += frame * out_cap;
         out_count += frame * 2;
         if (mirror_out) mirror_out += frame * out_cap;

@@ -644,3 +644,77 @@ def test_pipeline_depth_hint_changes_launch_sizes_not_results(oracle, ctx_factor
             p = oracle.Pyramid.build(frames[f], [4, 8], 30.0)
             assert results[1][0][f] == key(p.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 85.0)), f
             p.free()
+
+
+@pytest.mark.parametrize("T", [(4, 8), (4, 8, 8)])
+def test_refinement_as_one_frame_major_list(oracle, ctx_factory, case1, T):
+    """sbm_set_refine_order: the refinement pass walking the candidates of up to 64 frames as ONE frame-major list
+    (k_similarity_local ORDER 2; the default for batches whose planes exceed the L2s, e.g. BASELINE config 5) against the
+    per-frame slots: 70 frames = a group of 64 and a group of 6, frames without any candidate at the start, in the
+    middle and at the end of a group, 2- and 3-level pyramids (the 3-level one rewrites the list between the passes),
+    and a candidate list that overflows in some frames only (the overflow flag is published per frame)."""
+    import torch
+
+    from shape_based_matching_amd.templates import from_pyramids
+
+    dev = torch.device("cuda", 0)
+    L = len(T)
+    ts_all = case1["templates"]
+    pyrs = []
+    for t in range(300, 361, 6):
+        lv = []
+        for l in range(L):
+            src = ts_all.levels[t, min(l, 1)]
+            f = ts_all.features[src["feature_offset"]: src["feature_offset"] + src["n_features"]]
+            scale = 1 if l < 2 else 2
+            feats = np.stack([f["x"] // scale, f["y"] // scale, f["label"]], axis=1)
+            lv.append({"width": int(src["width"]) // scale, "height": int(src["height"]) // scale, "tl_x": 0, "tl_y": 0,
+                       "pyramid_level": l, "features": feats})
+        pyrs.append(lv)
+    ts = from_pyramids(pyrs, "t")
+    rows, cols, B = 512, 640, 70
+    base = np.ascontiguousarray(synth.embed(case1["test"], rows, cols, 20, 40)[:, :, 1])
+    frames = np.stack([np.roll(base, 4 * (b % 9), axis=1) for b in range(B)])
+    for b in (0, 31, 63, 64, 69):
+        frames[b] = 0
+    d_imgs = torch.from_numpy(frames).to(dev)
+    stream = torch.cuda.Stream(device=dev)
+    cap, rec, thr = 2048, MATCH_DTYPE.itemsize, 70.0
+    got = {}
+    for order in ("slots", "list"):
+        ctx = ctx_factory(T=T)
+        ctx.upload_templates(ts)
+        ctx.set_refine_order(order)
+        d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)
+        d_cnt = torch.full((B * 2,), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(2):  # the second call finds the counters as the first one left them
+            ctx.match_batch_device(d_imgs.data_ptr(), rows * cols, B, rows, cols, cols, 1, thr, d_out.data_ptr(), cap, d_cnt.data_ptr(),
+                                   stream=stream.cuda_stream)
+            stream.synchronize()
+        cnt = d_cnt.cpu().numpy().reshape(B, 2)
+        out = d_out.cpu().numpy().reshape(B, cap * rec)
+        assert (cnt[:, 1] == 0).all()
+        got[order] = [key(out[f].view(MATCH_DTYPE)[: cnt[f, 0]]) for f in range(B)]
+    assert got["list"] == got["slots"]
+    assert all(len(got["list"][b]) == 0 for b in (0, 31, 63, 64, 69)) and sum(len(x) for x in got["list"]) > B
+    for f in (1, 62, 68):
+        p = oracle.Pyramid.build(frames[f], list(T), 30.0)
+        assert got["list"][f] == key(p.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr)), f
+        p.free()
+    # overflow: four candidates per frame kept, flag 1 exactly where the coarse pass found more
+    flags = {}
+    for order in ("slots", "list"):
+        ctx = ctx_factory(T=T, max_candidates=4)
+        ctx.upload_templates(ts)
+        ctx.set_refine_order(order)
+        d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)
+        d_cnt = torch.full((B * 2,), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.match_batch_device(d_imgs.data_ptr(), rows * cols, B, rows, cols, cols, 1, thr, d_out.data_ptr(), cap, d_cnt.data_ptr(),
+                               stream=stream.cuda_stream)
+        stream.synchronize()
+        cnt = d_cnt.cpu().numpy().reshape(B, 2)
+        assert (cnt[:, 0] <= 4).all()
+        flags[order] = cnt[:, 1].tolist()
+    assert flags["list"] == flags["slots"] and 0 < sum(flags["list"]) < B

@@ -63,6 +63,7 @@ def run(n_cases, seed, verbose=True):
         ctx.upload_templates(ts)
         ctx.set_quantize_mode(qmode, hs)
         ctx.set_coarse_mode(cmode)
+        ctx.set_refine_order(str(rs.choice(["auto", "slots", "list"])))
         depth = int(rs.choice([1, 3]))  # round 3: throughput sizing of the launches (identical results)
         ctx.set_pipeline_depth(depth)
         # round 3: the entry point is drawn too -- the device batch, the pipelined host batch (sub-batches of 1..4), or the
