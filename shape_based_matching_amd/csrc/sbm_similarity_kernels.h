@@ -914,7 +914,7 @@ __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int6
 //      1024^2 frames 200 -> 207 us (tools/r03_local_order.sh), so the host picks by the planes' total size.
 //   (the frame as the SLOW dimension of order 0's grid was measured too: between the two on config 5, 1825 us)
 template <int COMPACT, int LW, int ORDER>
-__global__ __launch_bounds__(64 * LW) void k_similarity_local(
+__global__ __launch_bounds__(64 * LW) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_similarity_local(
     const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int l,
     const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
     const int32_t* __restrict__ raw_keep, const int32_t* __restrict__ class_idx,

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstring>
 #include <iostream>
 #include <mutex>
 #include <stdexcept>
