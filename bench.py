@@ -262,6 +262,12 @@ def main():
     # queues (default 4) and two streams that share a queue run their kernels in order -- 4 slots + the null stream
     # measure 14.5 us per frame, 7.4 with GPU_MAX_HW_QUEUES=8.
 
+    # stdout carries exactly ONE line, the JSON record: libraries that write to file descriptor 1 themselves (RCCL prints
+    # a version banner there when a communicator is created) are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -335,12 +341,27 @@ def main():
                 # single GPU: the last kernel stores the match list straight into pinned host memory
                 self.ctx.set_result_mirror(self.h_buf.data_ptr() + HDR, self.h_buf.data_ptr())
             elif native_gather:
-                # one RCCL communicator per slot, bootstrapped over torch.distributed
+                # one RCCL communicator per slot, bootstrapped over torch.distributed.  Every rank takes part in the
+                # broadcast whatever happened to it before; whether ALL ranks have a communicator is agreed on below
+                # (exchange_path), so that a rank that could not get one does not leave the others in a collective.
+                self.native_ok = True
                 uid = torch.zeros(128, dtype=torch.uint8, device=dev)
                 if rank == 0:
-                    uid.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
+                    try:
+                        uid.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
+                    except (capi.SbmError, OSError) as e:
+                        self.native_ok = False
+                        print(f"[bench] rank 0: no RCCL unique id from the library ({e})", file=sys.stderr)
+                ok = torch.tensor([1 if self.native_ok else 0], dtype=torch.int32, device=dev)
+                dist.broadcast(ok, src=0)
                 dist.broadcast(uid, src=0)
-                self.ctx.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+                self.native_ok = bool(int(ok.item()))
+                if self.native_ok:
+                    try:
+                        self.ctx.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+                    except (capi.SbmError, OSError) as e:
+                        self.native_ok = False
+                        print(f"[bench] rank {rank}: sbm_comm_init failed ({e})", file=sys.stderr)
 
         def run(self):
             s = self.stream.cuda_stream
@@ -357,6 +378,18 @@ def main():
                                                    self.d_buf.data_ptr(), cap, self.g_buf.data_ptr() if collective else 0,
                                                    gathered_mirror=self.h_buf.data_ptr(), n_bands=0 if world > 1 else n_bands,
                                                    stream=s)
+            elif native_gather and exchange_path[0] == "torch.distributed":
+                # the library's own communicator could not be set up on some rank: same kernels, the exchange step through
+                # torch.distributed (RCCL as well) on the same stream
+                if B > 1:
+                    self.ctx.match_batch_device(d_img.data_ptr(), FRAME_BYTES, B, ROWS, COLS, COLS * CH, CH, THRESHOLD,
+                                                self.d_buf.data_ptr() + HDR, cap, self.d_buf.data_ptr(), stream=s)
+                else:
+                    self.ctx.match_device(d_img.data_ptr(), ROWS, COLS, COLS * CH, CH, THRESHOLD, self.d_buf.data_ptr() + HDR, cap,
+                                          self.d_buf.data_ptr(), stream=s)
+                with torch.cuda.stream(self.stream):
+                    dist.all_gather_into_tensor(self.g_buf, self.d_buf)
+                    self.h_buf.copy_(self.g_buf, non_blocking=True)
             elif native_gather and B > 1:
                 self.ctx.match_batch_device_sharded(d_img.data_ptr(), FRAME_BYTES, B, ROWS, COLS, COLS * CH, CH, THRESHOLD,
                                                     self.d_buf.data_ptr(), cap, self.g_buf.data_ptr(),
@@ -381,8 +414,17 @@ def main():
             """[world][B][cap] match records"""
             return self.h_buf.numpy().reshape(world, BUF)[:, HDR:].copy().view(MATCH_DTYPE).reshape(world, B, cap)
 
+    exchange_path = ["library (ncclAllGather on the kernels' stream)" if native_gather else
+                     ("torch.distributed" if collective else "none")]
     slots = [Slot() for _ in range(max(1, args.inflight))]
     ctx = slots[0].ctx
+    if native_gather:
+        ok = torch.tensor([1 if all(getattr(sl, "native_ok", True) for sl in slots) else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and banded:
+            raise SystemExit("--partition bands needs the library's communicator on every rank (see stderr)")
+        if not banded and (int(ok.item()) == 0 or os.environ.get("SBM_BENCH_TORCH_GATHER")):
+            exchange_path[0] = "torch.distributed"
     if wl.stage == "match" and not os.environ.get("SBM_BENCH_LATENCY_SIZING"):
         for sl in slots:  # the slots' batches are in flight together: size the launches for throughput
             sl.ctx.set_pipeline_depth(len(slots))
@@ -690,6 +732,7 @@ def main():
             "us_per_frame": elapsed / args.steps / frames_per_step_total * 1e6,
             "frames_in_flight": len(active[0]) * B,
             "launch": launch,
+            "exchange": exchange_path[0],
             ("ms_per_step_one_frame_at_a_time" if B == 1 else "ms_per_step_one_batch_at_a_time"): single_ms,
             # SURVEY 8d's two times per frame, from the per-kernel pass (kernels alone on one stream):
             # t_match = all kernels, t_templ = the template loop (coarse + refinement) only
@@ -771,7 +814,9 @@ def main():
                 if capi.canonicalize(np.ascontiguousarray(cpu_list, MATCH_DTYPE).copy()).tobytes() != capi.canonicalize(matches.copy()).tobytes():
                     raise SystemExit("GPU match list of frame 0 differs from the CPU oracle's")
                 out["cpu_baseline"]["gpu_list_equals_cpu_list"] = True
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     for sl in slots:
         sl.ctx.close()
     if collective:
