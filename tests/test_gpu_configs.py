@@ -64,6 +64,44 @@ def test_config4_thousand_template_shard_of_the_full_set(oracle, ctx_factory):
     pyr.free()
 
 
+C3 = (2048, 3600, [63, 31], 260, 32)
+C4 = (4096, 36000, [8191, 4095], 1024, 16)
+
+
+@pytest.mark.parametrize("cfg,first,count,n_parts", [(C4, 4500, 4500, 4), (C4, 0, 36000, 8), (C3, 0, 3600, 8)],
+                         ids=["c4-one-rank-share", "c4-all-36000", "c3-all-3600"])
+def test_config3_config4_full_size_properties(ctx_factory, cfg, first, count, n_parts):
+    """BASELINE config 4 at the size ONE rank of the 8-GPU job runs it -- 4 500 of the 36 000 templates x 8191 / 4095 features
+    (templates 4500 .. 8999: 55 M features) -- and at its FULL stated size, all 36 000 templates on one GPU (442 M features:
+    5.3 GB of generated template data on the host, 6.6 GB in HBM), on 4096^2 maps -- far beyond what the oracle finishes in
+    seconds (and BASELINE config 3 at its full size, 2048^2 x 3600 templates x 63 / 31 features, the uint8 paths), so the
+    check is through properties the domain offers: (1) the planted templates of the range, and nothing else, come back
+    (synth.stage_b_fixed plants template k * n_total / n_plants; features that share a pixel keep the score just below 100); (2) the match list of the
+    whole range is the union of the lists of any partition of it (sbm_partition_templates, sbm_select_range): what template
+    sharding over GPUs relies on; (3) repeating the call gives the same list.  test_config4_thousand_template_shard_of_the_
+    full_set pins a 1024-template slice of the same set to the oracle."""
+    T = (4, 8)
+    side, n_total, nf, box, n_plants = cfg
+    maps, ts = synth.stage_b_fixed(1234, side, side, T, n_total, nf, templ_size=box, n_plants=n_plants, first=first, count=count)
+    assert ts.n_templates == count and int(ts.template_id[0]) == first
+    ctx = ctx_factory(T=T, max_candidates=1 << 22)
+    ctx.upload_templates(ts)
+    for l in range(2):
+        ctx.set_quantized(l, maps[l])
+    whole = multiset(ctx.match_templates(90.0))
+    assert whole == multiset(ctx.match_templates(90.0))
+    planted = {k * n_total // n_plants for k in range(n_plants)} & set(range(first, first + count))
+    assert len(planted) == n_plants * count // n_total
+    assert {r[5] for r in whole} == planted and all(r[2] > 90.0 for r in whole)
+    parts = ctx.partition_templates(side, side, n_parts)
+    assert sum(c for _, c in parts) == count and parts[0][0] == 0 and len(parts) == n_parts
+    union = []
+    for f, c in parts:
+        ctx.select_range(f, c)
+        union += multiset(ctx.match_templates(90.0))
+    assert sorted(union) == whole
+
+
 def test_config5_one_frame_all_templates(oracle, ctx_factory):
     """1920 x 1072 (the 1080p frame cropped to multiples of 16, test.cpp:349-353), 1000 templates x 128 / 64"""
     run_stage_b(oracle, ctx_factory, 1072, 1920, 1000, [128, 64], 260, plant_every=40)
@@ -116,3 +154,74 @@ def test_set_quantized_then_batch_at_new_geometry(oracle, ctx_factory, case1):
         assert multiset(out[f].view(MATCH_DTYPE)[: cnt[f, 0]]) == multiset(want)
     assert len(want) > 0
     pyr.free()
+
+
+def test_config5_full_size_properties(ctx_factory, case1):
+    """BASELINE config 5 at its stated size: 64 frames of 1920 x 1072 x 3 (the tiled case1 image, shifted per frame, as
+    bench.py --config c5 makes them) x 1000 templates in ONE call -- the size at which the refinement pass walks the
+    candidates as one frame-major list (the batch's planes exceed the L2s).  Properties: every frame's list equals the
+    list the same frame gets in a 16-frame call (refinement by per-frame slots, other launch sizes) and, for a few
+    frames, the single-frame entry point's; no list overflows; frames 0 and 2 (shifted by 16 pixels = one period of every
+    stride of the pyramid) give the same number of matches away from the left and right borders."""
+    import torch
+
+    from shape_based_matching_amd.templates import TemplateSet
+
+    dev = torch.device("cuda", 0)
+    base = case1["templates"]
+    sets = []
+    for k, take in enumerate((360, 360, 280)):
+        s = base.subset(range(take))
+        s.class_ids = [f"test{k}"]
+        sets.append(s)
+    ts = TemplateSet.concat(sets)
+    assert ts.n_templates == 1000
+    rows, cols, B = 1072, 1920, 64
+    img = case1["test"]
+    reps = (-(-rows // img.shape[0]), -(-cols // img.shape[1]), 1)
+    frame = np.ascontiguousarray(np.tile(img, reps)[:rows, :cols])
+    frames = np.stack([np.roll(frame, 8 * b, axis=1) for b in range(B)])
+    cap, rec, thr = 2048, MATCH_DTYPE.itemsize, 90.0
+    fs = rows * cols * 3
+    ctx = ctx_factory()
+    ctx.upload_templates(ts)
+    stream = torch.cuda.Stream(device=dev)
+    d_imgs = torch.from_numpy(frames).to(dev)
+    d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)
+    d_cnt = torch.full((2 * B,), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.match_batch_device(d_imgs.data_ptr(), fs, B, rows, cols, cols * 3, 3, thr, d_out.data_ptr(), cap, d_cnt.data_ptr(),
+                           stream=stream.cuda_stream)
+    stream.synchronize()
+    cnt = d_cnt.cpu().numpy().reshape(B, 2).copy()
+    out = d_out.cpu().numpy().reshape(B, cap * rec).copy()
+    assert (cnt[:, 1] == 0).all() and (cnt[:, 0] > 0).all() and (cnt[:, 0] <= cap).all()
+    whole = [key(out[b].view(MATCH_DTYPE)[: cnt[b, 0]]) for b in range(B)]
+    # the same frames, 16 per call
+    for g in range(0, B, 16):
+        d_cnt.fill_(-1)
+        torch.cuda.synchronize()
+        ctx.match_batch_device(d_imgs.data_ptr() + g * fs, fs, 16, rows, cols, cols * 3, 3, thr, d_out.data_ptr(), cap, d_cnt.data_ptr(),
+                               stream=stream.cuda_stream)
+        stream.synchronize()
+        c16 = d_cnt.cpu().numpy().reshape(B, 2)[:16]
+        o16 = d_out.cpu().numpy().reshape(B, cap * rec)[:16]
+        for b in range(16):
+            assert c16[b, 1] == 0 and key(o16[b].view(MATCH_DTYPE)[: c16[b, 0]]) == whole[g + b], g + b
+    one_out = torch.zeros(cap * rec, dtype=torch.uint8, device=dev)
+    one_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    for b in (0, 37, 63):
+        ctx.match_device(d_imgs.data_ptr() + b * fs, rows, cols, cols * 3, 3, thr, one_out.data_ptr(), cap, one_cnt.data_ptr(),
+                         stream=stream.cuda_stream)
+        stream.synchronize()
+        n = int(one_cnt.cpu().numpy()[0])
+        assert key(one_out.cpu().numpy().view(MATCH_DTYPE)[:n]) == whole[b], b
+    # a shift by 16 pixels moves every interior match by 16 pixels
+    def interior(recs, shift):
+        return sorted((r[0] - shift, r[1], r[3], r[4], r[5]) for r in recs if 400 + shift <= r[0] < cols - 700 + shift)
+
+    assert interior(whole[0], 0) == interior(whole[2], 16) and len(interior(whole[0], 0)) > 0
+
+
+def key(recs):
+    return sorted(np.ascontiguousarray(recs, MATCH_DTYPE).tolist())
