@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised end-to-end check of the batch entry point against the CPU oracle (GPU box; test infrastructure).
-Random frame geometry (multiples of 16), channel count, batch size, template subset, threshold, mask, gradient-kernel
-mode and coarse-pass kernel; every frame's match multiset must equal the oracle's.
+Random frame geometry (multiples of 16), pyramid, channel count, batch size, template subset, threshold, mask, gradient-kernel
+mode, coarse-pass kernel, refinement order and entry point; every frame's match multiset must equal the oracle's.
 usage: python tools/fuzz_match.py [n_cases] [seed]"""
 import os
 import sys
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import oracle as O  # noqa: E402
 from shape_based_matching_amd import capi, synth  # noqa: E402
-from shape_based_matching_amd.templates import MATCH_DTYPE, TemplateSet  # noqa: E402
+from shape_based_matching_amd.templates import MATCH_DTYPE, TemplateSet, from_pyramids  # noqa: E402
 
 
 def multiset(recs):
@@ -34,11 +34,29 @@ def run(n_cases, seed, verbose=True):
     for case in range(n_cases):
         rows = 16 * int(rs.randint(30, 70))
         cols = 64 * int(rs.randint(7, 18))  # the batch entry point wants (cols / T) % 4 == 0 at every level
+        # round 3: the pyramid is drawn too (the batch entry point takes T in {4, 8}); three levels need the geometry to
+        # stay 4-cell aligned one level further down
+        T = [(4, 8), (4, 8), (4, 8), (4, 8), (4,), (8,), (8, 8), (4, 4), (4, 8, 8)][int(rs.randint(0, 9))]
+        if len(T) == 3:
+            rows, cols = (rows + 31) // 32 * 32, (cols + 127) // 128 * 128
         ch = int(rs.choice([1, 3]))
         B = int(rs.randint(1, 10))
         n_t = int(rs.choice([1, 3, 7, 30, 90, 200]))
         idx = sorted(rs.choice(all_ts.n_templates, n_t, replace=False).tolist())
         ts = all_ts.subset(idx)
+        if T != (4, 8):  # the fixture's 2-level templates re-cut to the pyramid: level l from fixture level min(l, 1), halved below
+            pyrs = []
+            for t in idx:
+                lv = []
+                for l in range(len(T)):
+                    src = all_ts.levels[t, min(l, 1)]
+                    f = all_ts.features[src["feature_offset"]: src["feature_offset"] + src["n_features"]]
+                    scale = 1 if l < 2 else 2
+                    feats = np.stack([f["x"] // scale, f["y"] // scale, f["label"]], axis=1)
+                    lv.append({"width": int(src["width"]) // scale, "height": int(src["height"]) // scale, "tl_x": 0, "tl_y": 0,
+                               "pyramid_level": l, "features": feats})
+                pyrs.append(lv)
+            ts = from_pyramids(pyrs, "t")
         thr = float(rs.choice([55.0, 70.0, 80.0, 88.0, 93.0, 98.0]))
         kind = rs.choice(["embed", "tile", "scene"])
         frames = []
@@ -59,7 +77,7 @@ def run(n_cases, seed, verbose=True):
         cmode = str(rs.choice(["", "block", "wave"]))
         qmode = str(rs.choice(["auto", "tile", "stream"]))
         hs = int(rs.choice([0, 6, 8, 16, 28]))
-        ctx = capi.Context(T=(4, 8), weak_threshold=30.0, device_id=0)
+        ctx = capi.Context(T=T, weak_threshold=30.0, device_id=0)
         ctx.upload_templates(ts)
         ctx.set_quantize_mode(qmode, hs)
         ctx.set_coarse_mode(cmode)
@@ -72,7 +90,7 @@ def run(n_cases, seed, verbose=True):
         n_bands = 0
         if entry == "banded":
             ok = [n for n in (2, 3, 4, 5, 6, 8) if (rows // 2) % n == 0 and ((rows // 2) // n) % 2 == 0 and rows % n == 0 and (rows // n) % 2 == 0]
-            if qmode == "tile" or not ok:
+            if qmode == "tile" or not ok or T != (4, 8):
                 entry = "device"
             else:
                 n_bands = int(rs.choice(ok))
@@ -100,9 +118,9 @@ def run(n_cases, seed, verbose=True):
             h = d_buf.cpu().numpy()
             cnt = h[: 8 * B].view(np.int32).reshape(B, 2)
             out = h[hdr:].reshape(B, cap * rec)
-        desc = (case, rows, cols, ch, B, n_t, thr, kind, mask is not None, cmode, qmode, hs, depth, entry, n_bands)
+        desc = (case, T, rows, cols, ch, B, n_t, thr, kind, mask is not None, cmode, qmode, hs, depth, entry, n_bands)
         for f in range(B):
-            pyr = O.Pyramid.build(frames[f], [4, 8], 30.0, mask=mask)
+            pyr = O.Pyramid.build(frames[f], list(T), 30.0, mask=mask)
             want = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr, n_threads=min(16, os.cpu_count() or 1))
             pyr.free()
             if len(want) > cap:
