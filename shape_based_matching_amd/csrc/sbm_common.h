@@ -8,6 +8,16 @@
 
 namespace sbm {
 
+// Issue priority of the waves of the kernels that mostly WAIT (linear memories, coarse pass, refinement pass) above the
+// gradient kernel's (default 0).  With several batches in flight these kernels share SIMDs with gradient waves that
+// could issue a vector instruction every cycle; at equal priority their few instructions -- the ones that put the next
+// loads in flight -- queue behind that stream, their waves live longer and hold their slots and registers longer.
+// Measured (tools/r03_ab_prio.sh, three batches in flight): scene frame 115.2 -> 112.6 us per step, tiled frame 144.7 ->
+// 136.9; priorities 1 and 3 alike, a raised priority for the small level-1 gradient launch adds nothing.  A kernel that
+// runs alone is unaffected.
+__device__ __forceinline__ void raise_wave_priority() { __builtin_amdgcn_s_setprio(1); }
+
+
 // per (template, level) record on the device
 struct DevTL {
     int32_t width, height, nf, feat_off;

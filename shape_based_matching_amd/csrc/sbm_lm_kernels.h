@@ -272,6 +272,7 @@ struct LmArgs {
 
 __global__ __launch_bounds__(256) void k_build_lm_rows(const LmArgs a)
 {
+    raise_wave_priority();
     __shared__ uint32_t s_tile[8 * 256]; // strip levels: the workgroup's spread dwords, [tx][strip][row][4 cells]
     const size_t frame = blockIdx.y; // batch of frames: one grid row each
     if (blockIdx.x == 0 && a.counters) {

@@ -558,6 +558,7 @@ __global__ __launch_bounds__(256) void k_similarity_coarse_wave(
     const int32_t* __restrict__ class_idx, const int32_t* __restrict__ template_id, Cand* __restrict__ cands,
     int32_t* __restrict__ counters, int cap, int64_t lm_fs)
 {
+    raise_wave_priority();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int chunk_id, slot4, frame;
     coarse_block_item(chunk_id, slot4, frame);
@@ -923,6 +924,7 @@ __global__ __launch_bounds__(64 * LW) __attribute__((amdgpu_waves_per_eu(6, 6)))
     int out_cap, sbm_match_rec* __restrict__ mirror_out, int32_t* __restrict__ mirror_count, int collect_stats,
     int64_t lm_fs, const uint8_t* __restrict__ flabel, const uint16_t* __restrict__ fcls, int frames)
 {
+    raise_wave_priority();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // ORDER 2: lane = frame of the group: candidate counts, their running sums, and from those (frame, index) of entry g
     const int f_first = ORDER == 2 ? (int)blockIdx.y * 64 : 0;

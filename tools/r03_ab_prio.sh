@@ -1,0 +1,12 @@
+#!/bin/bash
+# wave priorities (s_setprio) of the kernels that wait on memory against the gradient kernel's: A/B of hand-made builds
+# tools/bin/libsbm_hip_{prev,new,v2,v3,v4}.so (prev: no priority; new: 3; v2: 3 + level-1 gradient 2; v3: 1; v4: 3 + level-1 gradient 1)
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r03_prio; mkdir -p $O
+cp shape_based_matching_amd/libsbm_hip.so /tmp/keep.so
+for r in 1 2; do for v in prev new v2 v3 v4; do
+  cp tools/bin/libsbm_hip_$v.so shape_based_matching_amd/libsbm_hip.so
+  python bench.py --no-cpu-baseline --no-strong-estimate --no-extra-frames > $O/${v}_$r.json 2>$O/err.log || tail -3 $O/err.log
+  python bench.py --no-cpu-baseline --no-strong-estimate --no-extra-frames --frame tiled > $O/${v}_tiled_$r.json 2>$O/err.log || tail -3 $O/err.log
+done; done
+cp /tmp/keep.so shape_based_matching_amd/libsbm_hip.so
+python tools/kshow.py $O/*.json | grep value
