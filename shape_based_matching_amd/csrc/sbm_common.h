@@ -16,6 +16,10 @@ namespace sbm {
 // 136.9; priorities 1 and 3 alike, a raised priority for the small level-1 gradient launch adds nothing.  A kernel that
 // runs alone is unaffected.
 __device__ __forceinline__ void raise_wave_priority() { __builtin_amdgcn_s_setprio(1); }
+// ... and the one-workgroup kernels between them (counter reset, list copy) above those: at the default priority a
+// 64-thread reset queued behind another batch's coarse pass waits for it to END (BASELINE config 3 with two batches in
+// flight: 45 -> 74 us per step when only the waiting kernels were raised)
+__device__ __forceinline__ void top_wave_priority() { __builtin_amdgcn_s_setprio(3); }
 
 
 // per (template, level) record on the device

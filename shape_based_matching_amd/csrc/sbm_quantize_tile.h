@@ -692,6 +692,7 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restr
 __global__ __launch_bounds__(256) void k_resize_mask(const uint8_t* __restrict__ src, int rows, int cols,
                                                      uint8_t* __restrict__ dst, int drows, int dcols)
 {
+    top_wave_priority(); // a small kernel between two gradient launches of its batch
     const double fx = (double)cols / dcols, fy = (double)rows / drows;
     const int n = drows * dcols;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {

@@ -387,6 +387,7 @@ __device__ __forceinline__ bool accumulate_features16_pruned(const uint8_t* __re
 // plain byte copy (gathered match lists -> pinned host mirror); n multiple of 8 by construction
 __global__ __launch_bounds__(256) void k_copy_bytes(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t n)
 {
+    top_wave_priority();
     const size_t n8 = n / 8;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256)
         ((uint64_t*)dst)[i] = ((const uint64_t*)src)[i];
@@ -396,6 +397,7 @@ __global__ __launch_bounds__(256) void k_copy_bytes(const uint8_t* __restrict__ 
 // zero the per-call counters (one launch instead of two memsets)
 __global__ void k_reset(int32_t* __restrict__ counters, int32_t* __restrict__ out_count)
 {
+    top_wave_priority();
     for (int i = threadIdx.x; i < CTR_STRIDE; i += blockDim.x) counters[i] = 0; // layout: sbm_common.h CTR_*
     if (threadIdx.x < 2) out_count[threadIdx.x] = 0;
 }
@@ -462,6 +464,7 @@ __global__ __launch_bounds__(256) void k_similarity_coarse(
     const int32_t* __restrict__ class_idx, const int32_t* __restrict__ template_id, Cand* __restrict__ cands,
     int32_t* __restrict__ counters, int cap, int64_t lm_fs)
 {
+    raise_wave_priority();
     // batch of frames: per-frame linear memories, candidate list and counters
     __shared__ uint32_t s_red[4][8][64];
     __shared__ int s_alive[4];
@@ -1086,6 +1089,7 @@ __global__ __launch_bounds__(256) void k_emit_coarse(const Cand* __restrict__ ca
                                                      sbm_match_rec* __restrict__ mirror_out,
                                                      int32_t* __restrict__ mirror_count)
 {
+    raise_wave_priority();
     { // batch of frames: frame = blockIdx.y
         const size_t frame = blockIdx.y;
         cands += frame * cand_cap;
