@@ -927,7 +927,12 @@ __global__ __launch_bounds__(64 * LW) __attribute__((amdgpu_waves_per_eu(6, 6)))
     int out_cap, sbm_match_rec* __restrict__ mirror_out, int32_t* __restrict__ mirror_count, int collect_stats,
     int64_t lm_fs, const uint8_t* __restrict__ flabel, const uint16_t* __restrict__ fcls, int frames)
 {
-    raise_wave_priority();
+    // The refinement pass runs at the gradient kernels' priority when it follows them (a match call: beside other batches'
+    // gradient launches its few working workgroups at a raised priority cost more than they gain -- scene frame 111.9 ->
+    // 110.2 us per step without, tools/r03_ab3.sh), and at the raised one in a template-loop-only call, where the other
+    // batches in flight run coarse passes (flag bit 1 of collect_stats).
+    if (collect_stats & 2) raise_wave_priority();
+    collect_stats &= 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // ORDER 2: lane = frame of the group: candidate counts, their running sums, and from those (frame, index) of entry g
     const int f_first = ORDER == 2 ? (int)blockIdx.y * 64 : 0;
