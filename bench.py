@@ -459,6 +459,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    last_issue_s = [0.0]
+
     def timed(n_warm, n_steps, which=None):
         """K steps bracketed by barrier + synchronize; max over ranks"""
         run = step if which is None else which
@@ -468,6 +470,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(n_steps):
             run()
+        last_issue_s[0] = time.perf_counter() - t0  # host time to ENQUEUE the steps (nothing waited for yet)
         fence()
         el = time.perf_counter() - t0
         if collective:
@@ -498,10 +501,14 @@ def main():
         launch["path"] = "hipGraph replay (SBM_GRAPH)"
     elif wl.stage == "match" and B > 1 and not banded and not os.environ.get("SBM_BENCH_NO_ADAPT"):
         t_stream = probe()
+        issue_stream = last_issue_s[0] / 40 * 1e6
         for sl in slots:
             sl.ctx.set_graph_mode(True)
         t_graph = probe()
         launch["probe_us_per_step"] = {"stream launches": round(t_stream, 1), "hipGraph replay": round(t_graph, 1)}
+        # host time spent inside the launch calls of a step (no synchronisation): tells a slow GPU from a blocking host
+        launch["probe_host_enqueue_us_per_step"] = {"stream launches": round(issue_stream, 1),
+                                                    "hipGraph replay": round(last_issue_s[0] / 40 * 1e6, 1)}
         if t_graph < 0.95 * t_stream:
             launch["path"] = "hipGraph replay"
         else:
