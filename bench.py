@@ -509,11 +509,16 @@ def main():
         # host time spent inside the launch calls of a step (no synchronisation): tells a slow GPU from a blocking host
         launch["probe_host_enqueue_us_per_step"] = {"stream launches": round(issue_stream, 1),
                                                     "hipGraph replay": round(last_issue_s[0] / 40 * 1e6, 1)}
-        if t_graph < 0.95 * t_stream:
-            launch["path"] = "hipGraph replay"
-        else:
+        # Replay of the captured graphs unless stream launches are clearly faster: with four slots the two measure the same
+        # (109.3 - 110.4 against 109.7 - 111.1 us per step, six processes each: tools/r03_graph_vs_stream.sh), and about one
+        # process in eight runs its stream launches in a slow multi-stream mode (0.5 - 1.8 ms per step; mildly, 5 %, in
+        # others) that replay does not have
+        prefer_stream = os.environ.get("SBM_BENCH_PREFER") == "stream"  # A/B of the tie rule
+        if t_stream < 0.95 * t_graph or (prefer_stream and t_graph >= 0.95 * t_stream):
             for sl in slots:
                 sl.ctx.set_graph_mode(False)
+        else:
+            launch["path"] = "hipGraph replay"
         # fewer slots: three (four slot streams and the null stream are five streams on the stock runtime's four hardware
         # queues; a session in which two slots land on one queue is slower with four than with three), one
         best = min(t_stream, t_graph)
