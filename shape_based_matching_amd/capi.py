@@ -372,8 +372,9 @@ class Context:
         _check(lib().sbm_set_quantize_mode(self._h, {"auto": 0, "tile": 1, "stream": 2}[mode], rows_per_wave))
 
     def set_coarse_mode(self, mode: str = "auto"):
-        """coarse-pass kernel: "auto" (by launch size), "block" (four waves per item) or "wave"; identical candidates"""
-        _check(lib().sbm_set_coarse_mode(self._h, {"auto": 0, "": 0, "block": 1, "wave": 2}[mode]))
+        """coarse-pass kernel: "auto" (bit planes whenever the threshold is >= 0), "block" (bytes, four waves per item), "wave"
+        (bytes, one wave per item), "bits", "bytes" (block or wave by launch size); identical candidates"""
+        _check(lib().sbm_set_coarse_mode(self._h, {"auto": 0, "": 0, "block": 1, "wave": 2, "bits": 3, "bytes": 4}[mode]))
 
     def set_refine_order(self, order: str = "auto"):
         """refinement pass: "auto" (by the batch's plane size), "slots" (per-frame slots) or "list" (one frame-major list)"""

@@ -1,0 +1,230 @@
+// sbm_coarse_bits.h — the coarse pass on BIT PLANES (round 4), gfx950.
+// Reference functions replaced (file:line in ddcr/shape_based_matching):
+//   k_pack_bitplanes          computeResponseMaps' value set {0, 3, 4} (line2Dup.cpp:632-635, 687) as two bits per position
+//   k_similarity_coarse_bits  similarity / similarity_64 + candidate scan   line2Dup.cpp:807-858, 924-984, 1199-1216
+//
+// The reference adds one BYTE per (position, feature): response 4 if the feature's orientation o is set in the spread
+// byte, 3 if a circular neighbour of o is, else 0.  That byte carries two bits of information:
+//     any(o, p)   = response > 0        (plane o      of the bit linear memory)
+//     exact(o, p) = response == 4       (plane 8 + o)
+// and the reference's sum is   raw(p) = 3 * #any + #exact   over the template's features -- exactly.  Both planes use the
+// byte linear memory's flat order (bit j of plane o <-> byte j of LM[o], zero tail included), so a feature's byte offset
+// (k_prep_features) is also its bit offset and the row-overrun semantics of SURVEY 8a-6 carry over unchanged.
+//
+// Work item = (template, frame, 2016 consecutive positions): ONE wave, lane i owns positions 32 i .. 32 i + 31 (lane 63
+// only supplies lane 62's upper dword).  Per feature one 4-byte load per lane, the upper dword from the right neighbour
+// (DPP), one v_alignbit by the offset's bit misalignment (wave-uniform), and the 32 positions' bits enter a bit-sliced
+// carry-save counter (Harley-Seal: 7 full adders per 8 features, 3 instructions each).
+//
+//   Pass A (screening, exact pruning): counts MISSES of the any-plane.  raw <= 4 * (nf - misses), so a position with more
+//   than M = floor((4 nf - rmin) / 4) misses can never reach rmin.  The counter starts at 2^P - 1 - M: the carry out of
+//   its top plane IS "dead", kept sticky; every 8 features the wave stops if none of its positions is alive.
+//   Pass B (only for items with a survivor; only the lanes that hold one load): counts the exact-plane hits.
+//   Then per surviving position: raw = 3 * (nf - misses) + exact; candidates with raw >= rmin are appended.
+//
+// Nothing that could reach rmin is dropped and raw is the reference's sum: the candidate multiset equals the byte
+// kernels' (tests/test_gpu_coarse_pruning.py, tests/test_gpu_configs.py, tools/fuzz_match.py).
+#pragma once
+#include "sbm_common.h"
+#include "sbm_similarity_kernels.h"
+
+namespace sbm {
+
+constexpr int CB_POS = 63 * 32; // positions per work item
+
+// byte planes -> bit planes, flat: thread = 32 consecutive positions of one orientation plane of one frame.
+// n_dwords = dwords of one bit plane that hold data (the tail stays zero from the allocation).
+__global__ __launch_bounds__(256) void k_pack_bitplanes(const uint8_t* __restrict__ lm, int64_t lm_stride, int64_t lm_fs,
+                                                        uint32_t* __restrict__ blm, int64_t blm_fs_dwords, int n_dwords)
+{
+    raise_wave_priority();
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= n_dwords) return;
+    const int o = blockIdx.y;
+    const size_t frame = blockIdx.z;
+    const uint4* src = (const uint4*)(lm + frame * lm_fs + (size_t)o * lm_stride + (size_t)d * 32);
+    const uint4 a = src[0], b = src[1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t any = 0, exact = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        // response bytes are 0, 3 (0b011) or 4 (0b100): bit 2 = exact, bit 2 | bit 0 = any
+        uint32_t e = (w[i] >> 2) & 0x01010101u, n = (w[i] | (w[i] >> 2)) & 0x01010101u;
+        e |= e >> 7;  // byte 1's flag -> bit 1 (and byte 3's -> bit 17)
+        e |= e >> 14; // byte 2's -> bit 2, byte 3's -> bit 3
+        n |= n >> 7;
+        n |= n >> 14;
+        exact |= (e & 15u) << (4 * i);
+        any |= (n & 15u) << (4 * i);
+    }
+    const int64_t plane_dwords = lm_stride >> 5;
+    uint32_t* dst = blm + frame * blm_fs_dwords;
+    dst[(int64_t)o * plane_dwords + d] = any;
+    dst[(int64_t)(8 + o) * plane_dwords + d] = exact;
+}
+
+// full adder on 32 bit-slices: (h, l) = a + b + c
+#define SBM_CSA(h, l, a, b, c)                       \
+    do {                                             \
+        const uint32_t u_ = (a) ^ (b);               \
+        (h) = (u_ & (c)) | (~u_ & (a)); /* v_bfi */  \
+        (l) = u_ ^ (c);                              \
+    } while (0)
+
+// add eight 1-bit slices x[0..7] to the bit-sliced counter c[0..P-1]; returns the carry out of the top plane
+template <int P>
+__device__ __forceinline__ uint32_t bitslice_add8(uint32_t (&c)[P], const uint32_t (&x)[8])
+{
+    uint32_t t0, t1, f0, f1, e;
+    SBM_CSA(t0, c[0], c[0], x[0], x[1]);
+    SBM_CSA(t1, c[0], c[0], x[2], x[3]);
+    SBM_CSA(f0, c[1], c[1], t0, t1);
+    SBM_CSA(t0, c[0], c[0], x[4], x[5]);
+    SBM_CSA(t1, c[0], c[0], x[6], x[7]);
+    SBM_CSA(f1, c[1], c[1], t0, t1);
+    SBM_CSA(e, c[2], c[2], f0, f1);
+#pragma unroll
+    for (int p = 3; p < P; ++p) { // ripple the eights
+        const uint32_t t = c[p] & e;
+        c[p] ^= e;
+        e = t;
+    }
+    return e;
+}
+
+// One pass over the template's nf features on one bit-plane set.  ub: the plane set of this frame (wave-uniform);
+// li: this lane's dword of bit 0 of the item (item base / 32 + lane), or 0 for a lane whose loads do not matter (it
+// then reads the features' own first dwords: one more cache line per load, no branch).  MISSES: count zero bits and
+// stop when every position is dead, else count one bits.
+// soff: the template's feature offsets (bits == bytes, see above); sel: the first 64 of them, one per lane.
+// Returns false when pass A ended with no position alive.
+template <int P, bool MISSES>
+__device__ __forceinline__ bool bit_pass(const uint32_t* __restrict__ ub, uint32_t li, const int32_t* __restrict__ soff, int sel, int nf,
+                                         int zero_off, uint32_t (&c)[P], uint32_t& dead)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t li4 = li << 2;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ub, 0, 0x7fffffff, 0x00020000);
+    // eight features: loads first (all in flight together), then the arithmetic.  TAIL: features g + k >= nf are padding
+    // (their offsets point at the zero tail) and must not count as misses.
+    auto batch = [&](int g, auto tail) {
+        constexpr bool TAIL = decltype(tail)::value;
+        uint32_t lo[8];
+        int sh[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane(sel, (g + k) & 63);
+            sh[k] = (int)(o & 31u);
+            // buffer load: plane set (resource) + this lane's byte offset (VGPR) + the feature's dword (SGPR): no address arithmetic
+            lo[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)li4, (int)((o >> 5) << 2), 0);
+        }
+        uint32_t x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            // lane i's upper dword = lane i+1's load (wave_shl:1; lane 63 reads 0 -- it owns no position)
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo[k], 0x130, 0xf, 0xf, true);
+            const uint32_t v = __builtin_amdgcn_alignbit(hi, lo[k], (uint32_t)sh[k]);
+            x[k] = MISSES ? ~v : v;
+            if (TAIL && g + k >= nf) x[k] = 0u; // wave-uniform
+        }
+        const uint32_t carry = bitslice_add8<P>(c, x);
+        if (MISSES) dead |= carry;
+    };
+    int g = 0;
+    for (; g + 8 <= nf; g += 8) {
+        if (g && (g & 63) == 0) sel = g + lane < nf ? soff[g + lane] : zero_off; // next 64 offsets
+        batch(g, std::false_type{});
+        if (MISSES && __builtin_amdgcn_ballot_w64(~dead != 0u) == 0ull) return false;
+    }
+    if (g < nf) {
+        if (g && (g & 63) == 0) sel = g + lane < nf ? soff[g + lane] : zero_off;
+        batch(g, std::true_type{});
+        if (MISSES && __builtin_amdgcn_ballot_w64(~dead != 0u) == 0ull) return false;
+    }
+    return true;
+}
+
+template <int P>
+__device__ __forceinline__ int bitslice_get(const uint32_t (&c)[P], int b)
+{
+    int v = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) v |= (int)((c[p] >> b) & 1u) << p;
+    return v;
+}
+
+// grid = (items of CB_POS positions, active templates / 4, frames); block = 4 waves = 4 template slots.
+// blm: [frames][16 planes][lm_stride / 32 dwords]; P: counter planes, 2^P > the largest nf of the launch.
+template <int P>
+__global__ __launch_bounds__(256) void k_similarity_coarse_bits(
+    const uint32_t* __restrict__ blm, int64_t lm_stride, int T, int W, int H, int L, int lc, const DevTL* __restrict__ tls,
+    const int32_t* __restrict__ soff, const CoarseItem* __restrict__ items, const int32_t* __restrict__ cfoff, int n_active,
+    const int32_t* __restrict__ raw_keep, const int32_t* __restrict__ class_idx, const int32_t* __restrict__ template_id,
+    Cand* __restrict__ cands, int32_t* __restrict__ counters, int cap, int64_t blm_fs_dwords)
+{
+    raise_wave_priority();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int chunk_id, slot4, frame;
+    coarse_block_item(chunk_id, slot4, frame);
+    const int templ_slot = __builtin_amdgcn_readfirstlane(slot4 * 4 + wave);
+    if (templ_slot >= n_active) return;
+    const int sel0 = cfoff[(size_t)templ_slot * 64 + lane];
+    const CoarseItem it = items[templ_slot];
+    const int nf = __builtin_amdgcn_readfirstlane(it.nf), rmin = __builtin_amdgcn_readfirstlane(it.rmin);
+    const int npos = __builtin_amdgcn_readfirstlane(it.npos);
+    const int base = chunk_id * CB_POS;
+    if (base >= npos || nf <= 0) return; // rmin >= 1 (host): positions past the span score 0 and are never candidates
+    const int M = (4 * nf - rmin) >> 2;  // misses a position can afford
+    if (4 * nf < rmin) return;
+    const int zero_off = (int)(7 * lm_stride + (int64_t)T * T * W * H);
+    // this lane's positions base + 32 lane + b, b < nvalid
+    int nvalid = npos - base - 32 * lane;
+    nvalid = lane == 63 ? 0 : (nvalid < 0 ? 0 : (nvalid > 32 ? 32 : nvalid));
+    const uint32_t valid = nvalid == 32 ? ~0u : ((1u << nvalid) - 1u);
+    const bool on = base + 32 * lane < npos + 32; // own positions or the left neighbour's upper dword
+    const uint32_t* ub = blm + (size_t)frame * blm_fs_dwords;
+    const uint32_t li = (uint32_t)((base >> 5) + lane);
+    const int32_t* so = soff + it.soff_base;
+
+    uint32_t ca[P];
+    const int bias = (1 << P) - 1 - M;
+#pragma unroll
+    for (int p = 0; p < P; ++p) ca[p] = (bias >> p) & 1 ? ~0u : 0u;
+    uint32_t dead = ~valid;
+    if (!bit_pass<P, true>(ub, on ? li : 0u, so, sel0, nf, zero_off, ca, dead)) return;
+
+    // survivors: exact hits of the lanes that hold one (and of their right neighbours, for the upper dword)
+    const uint32_t alive = ~dead;
+    const uint32_t left_alive = (uint32_t)__builtin_amdgcn_mov_dpp((int)alive, 0x138, 0xf, 0xf, true); // wave_shr:1
+    uint32_t ce[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) ce[p] = 0;
+    uint32_t unused = 0;
+    bit_pass<P, false>(ub + ((8 * lm_stride) >> 5), (alive | left_alive) != 0u ? li : 0u, so, sel0, nf, zero_off, ce, unused);
+
+    cands += (size_t)frame * cap;
+    counters += (size_t)frame * CTR_STRIDE;
+    const int offset = T / 2 + (T % 2 - 1);
+    uint32_t m = alive;
+    while (m) {
+        const int b = __builtin_ctz(m);
+        m &= m - 1;
+        const int misses = bitslice_get<P>(ca, b) - bias;
+        const int raw = 3 * (nf - misses) + bitslice_get<P>(ce, b);
+        if (raw >= rmin) {
+            const int j = base + 32 * lane + b;
+            const int idx = atomicAdd(&counters[0], 1);
+            if (idx < cap) {
+                Cand c;
+                c.t = it.t;
+                c.x = (j % W) * T + offset;
+                c.y = (j / W) * T + offset;
+                c.raw = raw;
+                cand_fill_next(c, tls, raw_keep, class_idx, template_id, L, lc - 1);
+                cands[idx] = c;
+            }
+        }
+    }
+}
+
+} // namespace sbm

@@ -20,3 +20,4 @@
 #include "sbm_quantize_tile.h"
 #include "sbm_lm_kernels.h"
 #include "sbm_similarity_kernels.h"
+#include "sbm_coarse_bits.h"

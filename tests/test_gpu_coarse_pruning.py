@@ -1,4 +1,4 @@
-"""-m gpu: the coarse pass's exact pruning and its two kernels (four waves per item / one wave per item).
+"""-m gpu: the coarse pass's exact pruning and its three kernels (bytes: four waves per item / one wave per item; bit planes).
 
 The coarse pass (similarity, line2Dup.cpp:807-858 / :924-984, scanned at :1199-1216) stops an item after a prefix of
 its features when no position can reach the threshold any more.  Nothing that could have reached the threshold may be
@@ -34,7 +34,7 @@ def forced_ctx():
         c.close()
 
 
-@pytest.mark.parametrize("mode", ["block", "wave"])
+@pytest.mark.parametrize("mode", ["block", "wave", "bits"])
 def test_case1_thresholds(oracle, forced_ctx, case1, mode):
     """131 / 71 features: thresholds 50 (no prefix short enough: unpruned) .. 99 (prefix of 8 features)"""
     ts = case1["templates"].subset(range(0, 360, 3))
@@ -52,7 +52,7 @@ def test_case1_thresholds(oracle, forced_ctx, case1, mode):
     assert n_lists[0] > n_lists[4] > 0
 
 
-@pytest.mark.parametrize("mode", ["block", "wave"])
+@pytest.mark.parametrize("mode", ["block", "wave", "bits"])
 def test_stage_b_small_and_huge_templates(oracle, forced_ctx, mode):
     """31 features at the coarse level (uint8 path, prefix 8) and 4095 (prefix 1024; the planted templates' items run
     the remaining 3071 features)"""
@@ -87,7 +87,7 @@ def test_batch_both_kernels_agree(oracle, forced_ctx, case1):
         pyr = oracle.Pyramid.build(frames[b], [4, 8], 30.0)
         wants.append(multiset(pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 88.0, n_threads=min(16, os.cpu_count() or 1))))
         pyr.free()
-    for mode in ("block", "wave"):
+    for mode in ("block", "wave", "bits"):
         ctx = forced_ctx(mode)
         ctx.upload_templates(ts)
         stream = torch.cuda.Stream(device=dev)
@@ -104,8 +104,9 @@ def test_batch_both_kernels_agree(oracle, forced_ctx, case1):
             assert multiset(recs[b, : cnt[b, 0]]) == wants[b], (mode, b)
 
 
+@pytest.mark.parametrize("mode", ["wave", "bits"])
 @pytest.mark.parametrize("n_templates,B", [(7, 3), (121, 5), (358, 2)])
-def test_wave_kernel_ragged_template_count_and_batch(oracle, forced_ctx, case1, n_templates, B):
+def test_wave_kernel_ragged_template_count_and_batch(oracle, forced_ctx, case1, n_templates, B, mode):
     """one wave per item, four template slots per workgroup: template counts that are not multiples of 4, batches
     without the frame -> XCD mapping (B not a multiple of 8), a frame geometry whose chunk count is not a multiple of 8"""
     import torch
@@ -119,7 +120,7 @@ def test_wave_kernel_ragged_template_count_and_batch(oracle, forced_ctx, case1, 
     frames = np.stack([np.roll(base, 24 * b, axis=1) for b in range(B)])
     cap, rec = 4096, MATCH_DTYPE.itemsize
     d_img = torch.from_numpy(frames).to(dev)
-    ctx = forced_ctx("wave")
+    ctx = forced_ctx(mode)
     ctx.upload_templates(ts)
     stream = torch.cuda.Stream(device=dev)
     d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)

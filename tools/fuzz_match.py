@@ -74,7 +74,7 @@ def run(n_cases, seed, verbose=True):
         if rs.randint(0, 4) == 0:
             mask = np.zeros((rows, cols), np.uint8)
             mask[rows // 8: rows - rows // 6, cols // 7: cols - cols // 9] = 255
-        cmode = str(rs.choice(["", "block", "wave"]))
+        cmode = str(rs.choice(["", "block", "wave", "bits", "bytes"]))
         qmode = str(rs.choice(["auto", "tile", "stream"]))
         hs = int(rs.choice([0, 6, 8, 16, 28]))
         ctx = capi.Context(T=T, weak_threshold=30.0, device_id=0)
