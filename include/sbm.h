@@ -277,6 +277,13 @@ int sbm_set_quantized(sbm_ctx* ctx, int32_t level, const uint8_t* quantized_host
 int sbm_get_quantized(sbm_ctx* ctx, int32_t level, uint8_t* out_host);
 int sbm_get_linear_memories(sbm_ctx* ctx, int32_t level, uint8_t* out_host, int64_t cap_bytes,
                             int64_t* lm_stride);
+/* The coarsest level's linear memories as BIT planes (round 4): what the coarse pass reads instead of the reference's
+ * one byte per (position, orientation) (similarity, line2Dup.cpp:843-856; values {0, 3, 4} of SIMILARITY_LUT :632-635).
+ * Per frame 16 planes of lm_stride BITS each, little-endian dwords, in the flat order of the byte linear memories:
+ * plane o (0..7): bit j = (LM[o][j] > 0); plane 8 + o: bit j = (LM[o][j] == 4).  frame: which frame of the last batch.
+ * out_host: 16 * lm_stride / 8 bytes.  Fails with SBM_ERR_STATE when the last call did not produce them (a threshold < 0,
+ * or sbm_set_coarse_mode picked a byte kernel).  A parity-test accessor. */
+int sbm_get_coarse_bitplanes(sbm_ctx* ctx, int32_t frame, uint8_t* out_host, int64_t cap_bytes);
 int sbm_level_dims(sbm_ctx* ctx, int32_t level, int32_t* rows, int32_t* cols);
 
 /* Second half of match(): Detector::matchClass over the selected templates

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "sbm_match_batch_device_banded", "sbm_pin_host_buffer", "sbm_unpin_host_buffer",
     "sbm_select_templates", "sbm_partition_templates", "sbm_match_sharded",
     "sbm_match_batch_host", "sbm_match_batch_host_begin", "sbm_match_batch_host_end", "sbm_extract_local_maxima",
-    "sbm_set_pipeline_depth", "sbm_set_coarse_mode", "sbm_set_refine_order",
+    "sbm_set_pipeline_depth", "sbm_set_coarse_mode", "sbm_set_refine_order", "sbm_get_coarse_bitplanes",
 ]
 
 
@@ -117,6 +117,7 @@ def lib() -> C.CDLL:
     L.sbm_set_quantized.argtypes = [vp, i32, vp, i32, i32]
     L.sbm_get_quantized.argtypes = [vp, i32, vp]
     L.sbm_get_linear_memories.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
+    L.sbm_get_coarse_bitplanes.argtypes = [vp, i32, vp, i64]
     L.sbm_level_dims.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.sbm_match_templates.argtypes = [vp, f32, vp, i64, C.POINTER(i64)]
     L.sbm_quantized_orientations.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]
@@ -413,6 +414,14 @@ class Context:
         _check(lib().sbm_get_linear_memories(self._h, level, None, 0, C.byref(s)))
         out = np.empty((8, s.value), np.uint8)
         _check(lib().sbm_get_linear_memories(self._h, level, _p(out), out.nbytes, C.byref(s)))
+        return out
+
+    def get_coarse_bitplanes(self, frame: int = 0) -> np.ndarray:
+        """[16][lm_stride / 8] bytes: the coarsest level's "response > 0" (0..7) and "response == 4" (8..15) bit planes"""
+        s = C.c_int64()
+        _check(lib().sbm_get_linear_memories(self._h, self.n_levels - 1, None, 0, C.byref(s)))
+        out = np.empty((16, s.value // 8), np.uint8)
+        _check(lib().sbm_get_coarse_bitplanes(self._h, frame, _p(out), out.nbytes))
         return out
 
     def match_templates(self, threshold: float) -> np.ndarray:

@@ -1,0 +1,142 @@
+// sbm_bitplane_math.h — register-level arithmetic on bit planes (round 4): the 32-byte -> 8-dword bit transpose of the
+// producer and the bit-sliced carry-save counters of the consumer.  Plain 32-bit integer code, host and device (the
+// host pass is what tests/emu compiles for the CPU suite).
+//
+// (1) 32 spread bytes -> 8 bit-plane dwords.
+// Part of the fused producer of the coarsest level's bit planes (k_build_lm_rows, sbm_lm_kernels.h); the reference
+// computes one response byte per orientation from the spread byte (computeResponseMaps, line2Dup.cpp:637-747), the
+// coarse pass on bit planes (sbm_coarse_bits.h) needs "bit o of the spread byte" of 32 consecutive cells as one dword.
+//
+// d[i] (i = 0..7) holds the spread bytes of cells 4i .. 4i+3 (byte j = cell 4i + j).  An element is addressed by
+// (register i = i2 i1 i0, position 8 j + o = j1 j0 o2 o1 o0); wanted is (register o, position 4 i + j = i2 i1 i0 j1 j0).
+// Five exchanges of one register-index bit with one position bit do it; the two that move a byte-index bit are byte
+// shuffles (v_perm_b32), the other three the classic masked-xor butterfly:
+//     i2 <-> j1 (pairs r, r+4)   i1 <-> j0 (pairs r, r+2)   i0 <-> o2 (pairs r, r+1, shift 4)
+//     j1 <-> o1 (pairs r, r+4, shift 2)   j0 <-> o0 (pairs r, r+2, shift 1)
+// after which register r = (o1 o0 o2) holds orientation o: see bitplane_reg().  76 instructions for 32 cells x 8 planes.
+#pragma once
+#include <stdint.h>
+
+namespace sbm {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t bp_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+#define SBM_BP_FN __device__ __forceinline__
+#else
+// host pass of the same header (tests/emu compiles it for the CPU): v_perm_b32's documented byte selection
+inline uint32_t bp_perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    const uint64_t src = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t s = (sel >> (8 * i)) & 0xff;
+        const uint32_t b = s < 8 ? (uint32_t)((src >> (8 * s)) & 0xff) : 0u; // selectors >= 8 are not used here
+        r |= b << (8 * i);
+    }
+    return r;
+}
+#if defined(__HIPCC__)
+#define SBM_BP_FN __host__ inline
+#else
+#define SBM_BP_FN inline
+#endif
+#endif
+
+#if defined(__HIPCC__)
+#define SBM_BP_HD __host__ __device__ __forceinline__
+#else
+#define SBM_BP_HD inline
+#endif
+
+// which register holds orientation o after bytes32_to_bitplanes
+SBM_BP_HD constexpr int bitplane_reg(int o) { return (((o >> 1) & 1) << 2) | ((o & 1) << 1) | ((o >> 2) & 1); }
+
+#if defined(__HIPCC__)
+__host__ __device__ __forceinline__
+#else
+inline
+#endif
+void bytes32_to_bitplanes(uint32_t (&d)[8])
+{
+    // i2 <-> j1: a' = {a.b0, a.b1, b.b0, b.b1}, b' = {a.b2, a.b3, b.b2, b.b3}
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t a = d[r], b = d[r + 4];
+        d[r] = bp_perm(b, a, 0x05040100u);
+        d[r + 4] = bp_perm(b, a, 0x07060302u);
+    }
+    // i1 <-> j0: a' = {a.b0, b.b0, a.b2, b.b2}, b' = {a.b1, b.b1, a.b3, b.b3}
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (q & 1) | ((q >> 1) << 2);
+        const uint32_t a = d[r], b = d[r + 2];
+        d[r] = bp_perm(b, a, 0x06020400u);
+        d[r + 2] = bp_perm(b, a, 0x07030501u);
+    }
+    // i0 <-> o2
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+        const uint32_t t = ((d[r] >> 4) ^ d[r + 1]) & 0x0f0f0f0fu;
+        d[r + 1] ^= t;
+        d[r] ^= t << 4;
+    }
+    // j1 <-> o1
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t t = ((d[r] >> 2) ^ d[r + 4]) & 0x33333333u;
+        d[r + 4] ^= t;
+        d[r] ^= t << 2;
+    }
+    // j0 <-> o0
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (q & 1) | ((q >> 1) << 2);
+        const uint32_t t = ((d[r] >> 1) ^ d[r + 2]) & 0x55555555u;
+        d[r + 2] ^= t;
+        d[r] ^= t << 1;
+    }
+}
+
+// (2) Bit-sliced counters of the coarse pass on bit planes (sbm_coarse_bits.h): c[p] holds bit p of 32 independent counters
+// (one per bit position).  Full adder on 32 slices: (h, l) = a + b + c; the compiler turns each line into one
+// v_bitop3_b32 on gfx950.
+#define SBM_CSA(h, l, a, b, c)                       \
+    do {                                             \
+        const uint32_t u_ = (a) ^ (b);               \
+        (h) = (u_ & (c)) | (~u_ & (a));              \
+        (l) = u_ ^ (c);                              \
+    } while (0)
+
+// add eight 1-bit slices x[0..7] to the counters c[0..P-1] (Harley-Seal: 7 full adders, then the eights ripple up);
+// returns the carry out of the top plane
+template <int P>
+SBM_BP_HD uint32_t bitslice_add8(uint32_t (&c)[P], const uint32_t (&x)[8])
+{
+    uint32_t t0, t1, f0, f1, e;
+    SBM_CSA(t0, c[0], c[0], x[0], x[1]);
+    SBM_CSA(t1, c[0], c[0], x[2], x[3]);
+    SBM_CSA(f0, c[1], c[1], t0, t1);
+    SBM_CSA(t0, c[0], c[0], x[4], x[5]);
+    SBM_CSA(t1, c[0], c[0], x[6], x[7]);
+    SBM_CSA(f1, c[1], c[1], t0, t1);
+    SBM_CSA(e, c[2], c[2], f0, f1);
+#pragma unroll
+    for (int p = 3; p < P; ++p) { // ripple the eights
+        const uint32_t t = c[p] & e;
+        c[p] ^= e;
+        e = t;
+    }
+    return e;
+}
+
+// counter of bit position b
+template <int P>
+SBM_BP_HD int bitslice_get(const uint32_t (&c)[P], int b)
+{
+    int v = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) v |= (int)((c[p] >> b) & 1u) << p;
+    return v;
+}
+
+} // namespace sbm

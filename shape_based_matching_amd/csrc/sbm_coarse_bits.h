@@ -14,7 +14,7 @@
 // Work item = (template, frame, 2016 consecutive positions): ONE wave, lane i owns positions 32 i .. 32 i + 31 (lane 63
 // only supplies lane 62's upper dword).  Per feature one 4-byte load per lane, the upper dword from the right neighbour
 // (DPP), one v_alignbit by the offset's bit misalignment (wave-uniform), and the 32 positions' bits enter a bit-sliced
-// carry-save counter (Harley-Seal: 7 full adders per 8 features, 3 instructions each).
+// carry-save counter (Harley-Seal: 7 full adders per 8 features, two v_bitop3_b32 each; sbm_bitplane_math.h).
 //
 //   Pass A (screening, exact pruning): counts MISSES of the any-plane.  raw <= 4 * (nf - misses), so a position with more
 //   than M = floor((4 nf - rmin) / 4) misses can never reach rmin.  The counter starts at 2^P - 1 - M: the carry out of
@@ -27,6 +27,7 @@
 #pragma once
 #include "sbm_common.h"
 #include "sbm_similarity_kernels.h"
+#include "sbm_bitplane_math.h"
 
 namespace sbm {
 
@@ -61,35 +62,6 @@ __global__ __launch_bounds__(256) void k_pack_bitplanes(const uint8_t* __restric
     uint32_t* dst = blm + frame * blm_fs_dwords;
     dst[(int64_t)o * plane_dwords + d] = any;
     dst[(int64_t)(8 + o) * plane_dwords + d] = exact;
-}
-
-// full adder on 32 bit-slices: (h, l) = a + b + c
-#define SBM_CSA(h, l, a, b, c)                       \
-    do {                                             \
-        const uint32_t u_ = (a) ^ (b);               \
-        (h) = (u_ & (c)) | (~u_ & (a)); /* v_bfi */  \
-        (l) = u_ ^ (c);                              \
-    } while (0)
-
-// add eight 1-bit slices x[0..7] to the bit-sliced counter c[0..P-1]; returns the carry out of the top plane
-template <int P>
-__device__ __forceinline__ uint32_t bitslice_add8(uint32_t (&c)[P], const uint32_t (&x)[8])
-{
-    uint32_t t0, t1, f0, f1, e;
-    SBM_CSA(t0, c[0], c[0], x[0], x[1]);
-    SBM_CSA(t1, c[0], c[0], x[2], x[3]);
-    SBM_CSA(f0, c[1], c[1], t0, t1);
-    SBM_CSA(t0, c[0], c[0], x[4], x[5]);
-    SBM_CSA(t1, c[0], c[0], x[6], x[7]);
-    SBM_CSA(f1, c[1], c[1], t0, t1);
-    SBM_CSA(e, c[2], c[2], f0, f1);
-#pragma unroll
-    for (int p = 3; p < P; ++p) { // ripple the eights
-        const uint32_t t = c[p] & e;
-        c[p] ^= e;
-        e = t;
-    }
-    return e;
 }
 
 // One pass over the template's nf features on one bit-plane set.  ub: the plane set of this frame (wave-uniform);
@@ -142,15 +114,6 @@ __device__ __forceinline__ bool bit_pass(const uint32_t* __restrict__ ub, uint32
         if (MISSES && __builtin_amdgcn_ballot_w64(~dead != 0u) == 0ull) return false;
     }
     return true;
-}
-
-template <int P>
-__device__ __forceinline__ int bitslice_get(const uint32_t (&c)[P], int b)
-{
-    int v = 0;
-#pragma unroll
-    for (int p = 0; p < P; ++p) v |= (int)((c[p] >> b) & 1u) << p;
-    return v;
 }
 
 // grid = (items of CB_POS positions, active templates / 4, frames); block = 4 waves = 4 template slots.

@@ -5,6 +5,7 @@
 //   k_expand_lm           the 8-plane form of a compact (spread-byte) level, on demand
 #pragma once
 #include "sbm_common.h"
+#include "sbm_bitplane_math.h"
 
 namespace sbm {
 
@@ -216,6 +217,34 @@ __device__ __forceinline__ void build_lm_rows_item(const uint8_t* __restrict__ q
             for (int tx = 0; tx < T; ++tx)
                 *(uint32_t*)(lm + lm_strip_offset(tile_ty * T + tx, gy2, S * 16 + (t & 3) * 4, W, H)) = s_tile[tx * 256 + t];
         }
+    } else if (compact == 3) {
+        // BIT PLANES of the coarsest level (round 4; read by k_similarity_coarse_bits): per orientation o one "response > 0"
+        // plane (spread bits o-1, o, o+1) and one "response == 4" plane (bit o), 1 bit per position in the byte planes' flat
+        // order -- 2 bytes per pixel instead of 8.  The wave's 64 lanes hold 256 CONSECUTIVE positions of sub-plane (ty, tx)
+        // for every tx (host: W * H % 256 == 0, so a wave never straddles two ty); the spread dwords cross LDS once
+        // ([tx][lane]), then lane (tx' = lane / 8, seg = lane % 8) reads the 32 bytes of cells 32 seg .. 32 seg + 31 of
+        // sub-column tx', transposes them into 8 dwords (bit b of dword o = bit o of cell b: bytes32_to_bitplanes) and
+        // stores 16 dwords.  T = 4: lanes 0..31.
+        const int t = (int)threadIdx.x, lane = t & 63, w0 = t & ~63;
+#pragma unroll
+        for (int tx = 0; tx < T; ++tx) s_tile[tx * 256 + t] = spread_dword(tx);
+        __builtin_amdgcn_wave_barrier(); // same wave writes and reads: LDS operations of a wave execute in order
+        const int txr = lane >> 3, seg = lane & 7;
+        if (txr < T) {
+            const uint4 lo4 = *(const uint4*)&s_tile[txr * 256 + w0 + seg * 8], hi4 = *(const uint4*)&s_tile[txr * 256 + w0 + seg * 8 + 4];
+            uint32_t d[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+            bytes32_to_bitplanes(d);
+            // first position of the wave: lane 0's cell (the wave's items are consecutive in (ty, gy, k) order)
+            const int64_t cell0 = __builtin_amdgcn_readfirstlane((int)cell);
+            const int64_t plane_dw = lm_stride >> 5; // lm_stride = bits per plane
+            uint32_t* out = (uint32_t*)lm + (((int64_t)(ty * T + txr) * WH + cell0) >> 5) + seg;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const uint32_t e = d[bitplane_reg(o)];
+                out[(int64_t)o * plane_dw] = d[bitplane_reg((o + 7) & 7)] | e | d[bitplane_reg((o + 1) & 7)];
+                out[(int64_t)(8 + o) * plane_dw] = e;
+            }
+        }
     } else if (compact) { // one plane of spread bytes: the reader applies the response LUT for its own orientation
 #pragma unroll
         for (int tx = 0; tx < T; ++tx) *(uint32_t*)(lm + (int64_t)(ty * T + tx) * WH + cell) = spread_dword(tx);
@@ -260,7 +289,8 @@ struct LmLevelArgs {
     int32_t block_begin; // first block of this level
     int64_t q_fs, lm_fs; // bytes from one frame of a batch to the next
     int32_t compact;     // 1: lm is ONE plane [T*T][W*H] of spread bytes (a level that only the refinement pass
-                         // reads): 1/8 of the stores and of the HBM write-back; 2: the same plane strip-interleaved
+                         // reads): 1/8 of the stores and of the HBM write-back; 2: the same plane strip-interleaved;
+                         // 3: lm is the coarsest level's 16 BIT planes (lm_stride bits each; sbm_coarse_bits.h)
     int32_t split;       // 8-plane levels: LM_FULL_SPLIT work items per (pixel row, 4 cells) instead of 1
 };
 struct LmArgs {

@@ -1,0 +1,58 @@
+"""CPU (not gpu): the register-level arithmetic of the coarse pass on bit planes
+(shape_based_matching_amd/csrc/sbm_bitplane_math.h, host pass compiled by tests/emu) against numpy.
+
+The reference adds one response byte per (position, feature) (similarity, line2Dup.cpp:843-856); the bit-plane kernels
+replace that by bit counts: the producer turns 32 spread bytes into 8 dwords of orientation bits, the consumer counts
+bits with bit-sliced carry-save counters whose top carry is "more misses than the threshold allows"."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+    L = C.CDLL(os.path.join(EMU_DIR, "libsbm_emu.so"))
+    L.sbm_emu_bytes32_to_bitplanes.argtypes = [C.c_void_p, C.c_void_p]
+    L.sbm_emu_bitslice_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.sbm_emu_bitslice_count.restype = C.c_uint32
+    return L
+
+
+def test_bytes32_to_bitplanes(emu):
+    rs = np.random.RandomState(5)
+    cases = [rs.randint(0, 256, 32).astype(np.uint8) for _ in range(500)]
+    cases += [np.zeros(32, np.uint8), np.full(32, 255, np.uint8), np.arange(32, dtype=np.uint8), (1 << (np.arange(32) % 8)).astype(np.uint8)]
+    for cells in cases:
+        out = np.zeros(8, np.uint32)
+        emu.sbm_emu_bytes32_to_bitplanes(cells.ctypes.data, out.ctypes.data)
+        for o in range(8):
+            want = int(sum(((int(cells[b]) >> o) & 1) << b for b in range(32)))
+            assert int(out[o]) == want, (o, cells)
+
+
+@pytest.mark.parametrize("P", [3, 7, 10, 13])
+def test_bitsliced_counters_and_sticky_overflow(emu, P):
+    rs = np.random.RandomState(P)
+    for n, density in ((8, 0.5), (64, 0.3), (72, 0.9), (1024, 0.62), (8192, 0.1), (8192, 0.97)):
+        if n > 8 * ((1 << P) - 1) and P < 13:
+            n = 8 * ((1 << P) - 1)
+        x = np.zeros(n, np.uint32)
+        bits = rs.rand(n, 32) < density
+        for b in range(32):
+            x |= bits[:, b].astype(np.uint32) << np.uint32(b)
+        total = bits.sum(axis=0)
+        for bias in (0, 1, (1 << P) - 1, rs.randint(0, 1 << P)):
+            counts = np.zeros(32, np.int32)
+            dead = emu.sbm_emu_bitslice_count(x.ctypes.data, n, P, bias, counts.ctypes.data)
+            assert np.array_equal(counts, (bias + total) % (1 << P))
+            # the sticky carry = "the counter passed 2^P at some point" = bias + count >= 2^P (counts only grow)
+            want_dead = sum(1 << b for b in range(32) if bias + total[b] >= (1 << P))
+            assert dead == want_dead, (n, density, bias)
