@@ -70,47 +70,63 @@ __global__ __launch_bounds__(256) void k_pack_bitplanes(const uint8_t* __restric
 // stop when every position is dead, else count one bits.
 // soff: the template's feature offsets (bits == bytes, see above); sel: the first 64 of them, one per lane.
 // Returns false when pass A ended with no position alive.
-template <int P, bool MISSES>
+template <int P, bool MISSES, bool WIDE>
 __device__ __forceinline__ bool bit_pass(const uint32_t* __restrict__ ub, uint32_t li, const int32_t* __restrict__ soff, int sel, int nf,
                                          int zero_off, uint32_t (&c)[P], uint32_t& dead)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t li4 = li << 2;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ub, 0, 0x7fffffff, 0x00020000);
-    // eight features: loads first (all in flight together), then the arithmetic.  TAIL: features g + k >= nf are padding
-    // (their offsets point at the zero tail) and must not count as misses.
-    auto batch = [&](int g, auto tail) {
+    // N = 8 or 16 features: loads first (all in flight together), then the arithmetic.  TAIL: features g + k >= nf are
+    // padding (their offsets point at the zero tail) and must not count as misses.  A batch never crosses a multiple of
+    // 64 features (the offsets of 64 features live in `sel`, one per lane).
+    auto batch = [&](int g, auto n_, auto tail) {
+        constexpr int N = decltype(n_)::value;
         constexpr bool TAIL = decltype(tail)::value;
-        uint32_t lo[8];
-        int sh[8];
+        uint32_t lo[N];
+        int sh[N];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < N; ++k) {
             const uint32_t o = (uint32_t)__builtin_amdgcn_readlane(sel, (g + k) & 63);
             sh[k] = (int)(o & 31u);
             // buffer load: plane set (resource) + this lane's byte offset (VGPR) + the feature's dword (SGPR): no address arithmetic
             lo[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)li4, (int)((o >> 5) << 2), 0);
         }
-        uint32_t x[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            // lane i's upper dword = lane i+1's load (wave_shl:1; lane 63 reads 0 -- it owns no position)
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo[k], 0x130, 0xf, 0xf, true);
-            const uint32_t v = __builtin_amdgcn_alignbit(hi, lo[k], (uint32_t)sh[k]);
-            x[k] = MISSES ? ~v : v;
-            if (TAIL && g + k >= nf) x[k] = 0u; // wave-uniform
+        for (int h = 0; h < N; h += 8) {
+            uint32_t x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                // lane i's upper dword = lane i+1's load (wave_shl:1; lane 63 reads 0 -- it owns no position)
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo[h + k], 0x130, 0xf, 0xf, true);
+                const uint32_t v = __builtin_amdgcn_alignbit(hi, lo[h + k], (uint32_t)sh[h + k]);
+                x[k] = MISSES ? ~v : v;
+                if (TAIL && g + h + k >= nf) x[k] = 0u; // wave-uniform
+            }
+            const uint32_t carry = bitslice_add8<P>(c, x);
+            if (MISSES) dead |= carry;
         }
-        const uint32_t carry = bitslice_add8<P>(c, x);
-        if (MISSES) dead |= carry;
     };
+    // the NEXT 64 offsets are fetched while the current 64 are being worked on
+    int sel_next = 64 + lane < nf ? soff[64 + lane] : zero_off;
     int g = 0;
-    for (; g + 8 <= nf; g += 8) {
-        if (g && (g & 63) == 0) sel = g + lane < nf ? soff[g + lane] : zero_off; // next 64 offsets
-        batch(g, std::false_type{});
-        if (MISSES && __builtin_amdgcn_ballot_w64(~dead != 0u) == 0ull) return false;
-    }
-    if (g < nf) {
-        if (g && (g & 63) == 0) sel = g + lane < nf ? soff[g + lane] : zero_off;
-        batch(g, std::true_type{});
+    while (g < nf) {
+        if (g && (g & 63) == 0) {
+            sel = sel_next;
+            sel_next = g + 64 + lane < nf ? soff[g + 64 + lane] : zero_off;
+        }
+        // pass A: two batches of 8 first (most items end there: empty background dies after M + 1 <= 8 misses), then 16s --
+        // twice the loads in flight for the items that go on; pass B never stops early: 16s throughout
+        const int left = nf - g;
+        if (!WIDE || (MISSES && g < 16) || left <= 8) {
+            if (left >= 8) batch(g, std::integral_constant<int, 8>{}, std::false_type{});
+            else batch(g, std::integral_constant<int, 8>{}, std::true_type{});
+            g += 8;
+        } else {
+            if (left >= 16) batch(g, std::integral_constant<int, 16>{}, std::false_type{});
+            else batch(g, std::integral_constant<int, 16>{}, std::true_type{});
+            g += 16;
+        }
         if (MISSES && __builtin_amdgcn_ballot_w64(~dead != 0u) == 0ull) return false;
     }
     return true;
@@ -118,7 +134,7 @@ __device__ __forceinline__ bool bit_pass(const uint32_t* __restrict__ ub, uint32
 
 // grid = (items of CB_POS positions, active templates / 4, frames); block = 4 waves = 4 template slots.
 // blm: [frames][16 planes][lm_stride / 32 dwords]; P: counter planes, 2^P > the largest nf of the launch.
-template <int P>
+template <int P, bool WIDE>
 __global__ __launch_bounds__(256) void k_similarity_coarse_bits(
     const uint32_t* __restrict__ blm, int64_t lm_stride, int T, int W, int H, int L, int lc, const DevTL* __restrict__ tls,
     const int32_t* __restrict__ soff, const CoarseItem* __restrict__ items, const int32_t* __restrict__ cfoff, int n_active,
@@ -154,7 +170,7 @@ __global__ __launch_bounds__(256) void k_similarity_coarse_bits(
 #pragma unroll
     for (int p = 0; p < P; ++p) ca[p] = (bias >> p) & 1 ? ~0u : 0u;
     uint32_t dead = ~valid;
-    if (!bit_pass<P, true>(ub, on ? li : 0u, so, sel0, nf, zero_off, ca, dead)) return;
+    if (!bit_pass<P, true, WIDE>(ub, on ? li : 0u, so, sel0, nf, zero_off, ca, dead)) return;
 
     // survivors: exact hits of the lanes that hold one (and of their right neighbours, for the upper dword)
     const uint32_t alive = ~dead;
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(256) void k_similarity_coarse_bits(
 #pragma unroll
     for (int p = 0; p < P; ++p) ce[p] = 0;
     uint32_t unused = 0;
-    bit_pass<P, false>(ub + ((8 * lm_stride) >> 5), (alive | left_alive) != 0u ? li : 0u, so, sel0, nf, zero_off, ce, unused);
+    bit_pass<P, false, WIDE>(ub + ((8 * lm_stride) >> 5), (alive | left_alive) != 0u ? li : 0u, so, sel0, nf, zero_off, ce, unused);
 
     cands += (size_t)frame * cap;
     counters += (size_t)frame * CTR_STRIDE;
