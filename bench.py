@@ -213,6 +213,43 @@ def cpu_baseline(ts, frame, budget_s: float = 12.0):
     }, last[0]
 
 
+def spawn_ranks(n_gpus):
+    """`python3 bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, BEFORE anything in
+    this process imports torch or touches a GPU (a process that has initialised the GPU must not be replaced or forked).
+    Same environment a `torch.distributed.run --nnodes=1 --nproc-per-node N` child sees (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*); rank 0's stdout -- the one JSON line -- is forwarded verbatim, every rank's stderr goes to ours.  Returns the
+    exit code: 0 only if every rank exited with 0."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_gpus), "LOCAL_WORLD_SIZE": str(n_gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "SBM_BENCH_SPAWNED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    print(f"[bench] spawned {n_gpus} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}", file=sys.stderr, flush=True)
+    out0 = procs[0].stdout.read()  # until rank 0 closes its stdout (it exits)
+    rcs = []
+    deadline = time.time() + 120.0  # rank 0 is gone: the others follow at once, or something is wrong with them
+    for r, p in enumerate(procs):
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()  # exactly the process we started
+            rcs.append(p.wait())
+            print(f"[bench] rank {r} (pid {p.pid}) did not exit with rank 0: killed", file=sys.stderr)
+    sys.stdout.buffer.write(out0)
+    sys.stdout.flush()
+    print(f"[bench] rank exit codes: {rcs}", file=sys.stderr, flush=True)
+    return next((rc if 0 < rc < 256 else 1 for rc in rcs if rc != 0), 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,6 +290,10 @@ def main():
     ap.add_argument("--no-strong-estimate", action="store_true", help="skip the measured strong-scaling estimate (N = 1)")
     ap.add_argument("--no-extra-frames", action="store_true", help="skip the secondary (textured / Stage-A) passes")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))  # no launcher around us: this process only starts the ranks and forwards rank 0's line
     if args.steps is None:
         args.steps = {"case1": 1000, "c3": 200, "c4": 10, "c5": 50}[args.config]
     if args.warmup is None:
@@ -283,9 +324,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher's WORLD_SIZE is {world}: make them agree (or unset WORLD_SIZE and "
+                         "let bench.py start its own ranks)")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+        raise SystemExit(f"bench.py rank {rank} of {world}: needs an MI355X: no GPU visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     collective = world > 1 or args.force_collective
@@ -317,7 +359,9 @@ def main():
     # one buffer, one collective, one copy
     HDR = (8 * B + 15) // 16 * 16
     BUF = HDR + B * cap * REC
-    native_gather = collective and wl.stage == "match"  # the library issues ncclAllGather on the kernels' stream
+    # ONE exchange path whatever the configuration: the library's own RCCL communicator (sbm_comm_init), its ncclAllGather
+    # issued by the sharded entry point on the kernels' stream.  torch.distributed (backend nccl = RCCL as well) only
+    # carries the 128-byte communicator id to the ranks and the barrier / max-over-ranks around the timed region.
     n_bands = world if (world > 1 and wl.partition == "bands") else (args.bands if world == 1 else 0)
     banded = wl.stage == "match" and n_bands > 0 and args.config == "case1"
     if banded and B < 1:
@@ -348,40 +392,38 @@ def main():
             if not collective and not banded:
                 # single GPU: the last kernel stores the match list straight into pinned host memory
                 self.ctx.set_result_mirror(self.h_buf.data_ptr() + HDR, self.h_buf.data_ptr())
-            elif native_gather:
-                # one RCCL communicator per slot, bootstrapped over torch.distributed.  Every rank takes part in the
-                # broadcast whatever happened to it before; whether ALL ranks have a communicator is agreed on below
-                # (exchange_path), so that a rank that could not get one does not leave the others in a collective.
-                self.native_ok = True
+            elif collective:
+                # one RCCL communicator per slot, its id made by rank 0 and broadcast.  Every rank takes part in both
+                # broadcasts whatever happened to it before; whether ALL ranks got a communicator is agreed on below.
+                self.comm_error = None
                 uid = torch.zeros(128, dtype=torch.uint8, device=dev)
                 if rank == 0:
                     try:
                         uid.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
                     except (capi.SbmError, OSError) as e:
-                        self.native_ok = False
-                        print(f"[bench] rank 0: no RCCL unique id from the library ({e})", file=sys.stderr)
-                ok = torch.tensor([1 if self.native_ok else 0], dtype=torch.int32, device=dev)
+                        self.comm_error = f"no RCCL unique id from the library ({e})"
+                ok = torch.tensor([0 if self.comm_error else 1], dtype=torch.int32, device=dev)
                 dist.broadcast(ok, src=0)
                 dist.broadcast(uid, src=0)
-                self.native_ok = bool(int(ok.item()))
-                if self.native_ok:
+                if not int(ok.item()):
+                    self.comm_error = self.comm_error or "rank 0 could not make a communicator id"
+                else:
                     try:
                         self.ctx.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
                     except (capi.SbmError, OSError) as e:
-                        self.native_ok = False
-                        print(f"[bench] rank {rank}: sbm_comm_init failed ({e})", file=sys.stderr)
+                        self.comm_error = f"sbm_comm_init failed ({e})"
 
         def run(self):
             s = self.stream.cuda_stream
             if ring_state[0] is not None:  # every call reads the next buffer of the input ring
                 img_sel[0] = ring_state[0][ring_state[1] % len(ring_state[0])]
                 ring_state[1] += 1
-            if wl.stage == "templates":
+            if wl.stage == "templates" and collective:
+                # template-loop configurations: this rank's template range on the resident pyramid + the exchange step
+                self.ctx.match_templates_device_sharded(THRESHOLD, self.d_buf.data_ptr(), cap, self.g_buf.data_ptr(),
+                                                        gathered_mirror=self.h_buf.data_ptr(), stream=s)
+            elif wl.stage == "templates":
                 self.ctx.match_templates_device(THRESHOLD, self.d_buf.data_ptr() + HDR, cap, self.d_buf.data_ptr(), stream=s)
-                if collective:  # template-loop configs: the exchange through torch.distributed (RCCL) on the same stream
-                    with torch.cuda.stream(self.stream):
-                        dist.all_gather_into_tensor(self.g_buf, self.d_buf)
-                        self.h_buf.copy_(self.g_buf, non_blocking=True)
             elif banded:
                 # build-sharded step: row bands of the gradient stage + all-gather of the orientation maps + template
                 # ranges + gather of the lists (one GPU: all bands here, one launch per band and level)
@@ -389,23 +431,11 @@ def main():
                                                    self.d_buf.data_ptr(), cap, self.g_buf.data_ptr() if collective else 0,
                                                    gathered_mirror=self.h_buf.data_ptr(), n_bands=0 if world > 1 else n_bands,
                                                    stream=s)
-            elif native_gather and exchange_path[0] == "torch.distributed":
-                # the library's own communicator could not be set up on some rank: same kernels, the exchange step through
-                # torch.distributed (RCCL as well) on the same stream
-                if B > 1:
-                    self.ctx.match_batch_device(img_sel[0].data_ptr(), FRAME_BYTES, B, ROWS, COLS, COLS * CH, CH, THRESHOLD,
-                                                self.d_buf.data_ptr() + HDR, cap, self.d_buf.data_ptr(), stream=s)
-                else:
-                    self.ctx.match_device(img_sel[0].data_ptr(), ROWS, COLS, COLS * CH, CH, THRESHOLD, self.d_buf.data_ptr() + HDR, cap,
-                                          self.d_buf.data_ptr(), stream=s)
-                with torch.cuda.stream(self.stream):
-                    dist.all_gather_into_tensor(self.g_buf, self.d_buf)
-                    self.h_buf.copy_(self.g_buf, non_blocking=True)
-            elif native_gather and B > 1:
+            elif collective and B > 1:
                 self.ctx.match_batch_device_sharded(img_sel[0].data_ptr(), FRAME_BYTES, B, ROWS, COLS, COLS * CH, CH, THRESHOLD,
                                                     self.d_buf.data_ptr(), cap, self.g_buf.data_ptr(),
                                                     gathered_mirror=self.h_buf.data_ptr(), stream=s)
-            elif native_gather:
+            elif collective:
                 # match of this rank's shard + the exchange step (ncclAllGather over xGMI, issued by the library on the
                 # same stream) + copy of the gathered lists into pinned host memory
                 self.ctx.match_device_sharded(img_sel[0].data_ptr(), ROWS, COLS, COLS * CH, CH, THRESHOLD, self.d_buf.data_ptr(), cap,
@@ -425,17 +455,19 @@ def main():
             """[world][B][cap] match records"""
             return self.h_buf.numpy().reshape(world, BUF)[:, HDR:].copy().view(MATCH_DTYPE).reshape(world, B, cap)
 
-    exchange_path = ["library (ncclAllGather on the kernels' stream)" if native_gather else
-                     ("torch.distributed" if collective else "none")]
+    exchange_path = ["library (ncclAllGather on the kernels' stream)" if collective else "none"]
     slots = [Slot() for _ in range(max(1, args.inflight))]
     ctx = slots[0].ctx
-    if native_gather:
-        ok = torch.tensor([1 if all(getattr(sl, "native_ok", True) for sl in slots) else 0], dtype=torch.int32, device=dev)
+    n_ranks_seen = 1
+    if collective:
+        # every rank must hold a communicator on every slot: agree on it, and stop all ranks together if one does not
+        errs = [sl.comm_error for sl in slots if sl.comm_error]
+        ok = torch.tensor([0 if errs else 1], dtype=torch.int32, device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0 and banded:
-            raise SystemExit("--partition bands needs the library's communicator on every rank (see stderr)")
-        if not banded and (int(ok.item()) == 0 or os.environ.get("SBM_BENCH_TORCH_GATHER")):
-            exchange_path[0] = "torch.distributed"
+        if int(ok.item()) == 0:
+            raise SystemExit(f"bench.py rank {rank} of {world}: the library's RCCL communicator could not be set up on every rank"
+                             + (f" (here: {errs[0]})" if errs else ""))
+        n_ranks_seen = ctx.comm_count()  # as RCCL reports it
     if wl.stage == "match" and not os.environ.get("SBM_BENCH_LATENCY_SIZING"):
         for sl in slots:  # the slots' batches are in flight together: size the launches for throughput
             sl.ctx.set_pipeline_depth(len(slots))
@@ -771,6 +803,7 @@ def main():
             "input_buffers": len(ring),
             "launch": launch,
             "exchange": exchange_path[0],
+            "n_ranks_seen": n_ranks_seen,
             ("ms_per_step_one_frame_at_a_time" if B == 1 else "ms_per_step_one_batch_at_a_time"): single_ms,
             # SURVEY 8d's two times per frame, from the per-kernel pass (kernels alone on one stream):
             # t_match = all kernels, t_templ = the template loop (coarse + refinement) only

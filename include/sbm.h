@@ -226,6 +226,14 @@ int sbm_set_result_mirror(sbm_ctx* ctx, void* mirror_out, void* mirror_count);
 int sbm_comm_unique_id(void* id_out);
 int sbm_comm_init(sbm_ctx* ctx, int32_t world, int32_t rank, const void* id);
 int sbm_comm_destroy(sbm_ctx* ctx);
+/* Size of the context's communicator as RCCL reports it (ncclCommCount): what a launcher records as "ranks seen". */
+int sbm_comm_count(sbm_ctx* ctx, int32_t* n_ranks);
+/* The template loop alone (sbm_match_templates_device: matchClass over the selected templates on the resident pyramid,
+ * line2Dup.cpp:1160-1297) followed by the same exchange step as sbm_match_device_sharded: d_local = 16-byte header
+ * {n_matches, overflow, 0, 0} + cap records, d_gathered = world such shards in rank order.  The sharded form of
+ * BASELINE configs 3 and 4 (template ranges over the ranks, pyramid resident on each). */
+int sbm_match_templates_device_sharded(sbm_ctx* ctx, float threshold, void* d_local, int64_t cap, void* d_gathered,
+                                       void* gathered_mirror, void* stream);
 int sbm_match_device_sharded(sbm_ctx* ctx, const void* d_img, int32_t rows, int32_t cols, int32_t stride,
                              int32_t channels, const void* d_mask, float threshold, void* d_local,
                              int64_t cap, void* d_gathered, void* gathered_mirror, void* stream);

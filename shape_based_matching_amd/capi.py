@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "sbm_select_templates", "sbm_partition_templates", "sbm_match_sharded",
     "sbm_match_batch_host", "sbm_match_batch_host_begin", "sbm_match_batch_host_end", "sbm_extract_local_maxima",
     "sbm_set_pipeline_depth", "sbm_set_coarse_mode", "sbm_set_refine_order", "sbm_get_coarse_bitplanes",
+    "sbm_comm_count", "sbm_match_templates_device_sharded",
 ]
 
 
@@ -139,6 +140,8 @@ def lib() -> C.CDLL:
     L.sbm_match_templates_device.argtypes = [vp, f32, vp, i64, vp, vp]
     L.sbm_comm_unique_id.argtypes = [vp]
     L.sbm_comm_init.argtypes = [vp, i32, i32, vp]
+    L.sbm_comm_count.argtypes = [vp, C.POINTER(i32)]
+    L.sbm_match_templates_device_sharded.argtypes = [vp, f32, vp, i64, vp, vp, vp]
     L.sbm_comm_destroy.argtypes = [vp]
     L.sbm_match_device_sharded.argtypes = [vp, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp, vp]
     L.sbm_match_batch_device_sharded.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp, vp]
@@ -276,6 +279,18 @@ class Context:
     def comm_init(self, world: int, rank: int, uid: bytes):
         assert len(uid) == 128
         _check(lib().sbm_comm_init(self._h, world, rank, C.c_char_p(uid)))
+
+    def comm_count(self) -> int:
+        """ranks of this context's communicator as RCCL reports them (ncclCommCount)"""
+        n = C.c_int32(0)
+        _check(lib().sbm_comm_count(self._h, C.byref(n)))
+        return int(n.value)
+
+    def match_templates_device_sharded(self, threshold: float, d_local: int, cap: int, d_gathered: int, gathered_mirror: int = 0,
+                                       stream: int = 0):
+        _check(lib().sbm_match_templates_device_sharded(self._h, C.c_float(threshold), C.c_void_p(d_local), cap, C.c_void_p(d_gathered),
+                                                        C.c_void_p(gathered_mirror) if gathered_mirror else None,
+                                                        C.c_void_p(stream) if stream else None))
 
     def match_device_sharded(self, d_img: int, rows: int, cols: int, stride: int, channels: int, threshold: float,
                              d_local: int, cap: int, d_gathered: int, gathered_mirror: int = 0, stream: int = 0,

@@ -151,6 +151,20 @@ def test_match_device_sharded_world1(oracle, ctx_factory, case1):
             got = buf[hdrb + f * cap * rec: hdrb + (f + 1) * cap * rec].view(MATCH_DTYPE)[: cnt[f, 0]]
             assert key(got) == key(wants[f]), f
 
+    # round 4: the communicator's size as RCCL reports it, and the template loop alone + the same exchange step (how the
+    # sharded runs of BASELINE configs 3 and 4 end a step) on the pyramid the last call left resident
+    assert ctx.comm_count() == 1
+    d_local = torch.zeros(hdr + cap * rec, dtype=torch.uint8, device=dev)
+    d_gath = torch.zeros(hdr + cap * rec, dtype=torch.uint8, device=dev)
+    h_gath = torch.zeros(hdr + cap * rec, dtype=torch.uint8).pin_memory()
+    ctx.match_templates_device_sharded(85.0, d_local.data_ptr(), cap, d_gath.data_ptr(), gathered_mirror=h_gath.data_ptr(),
+                                       stream=stream.cuda_stream)
+    stream.synchronize()
+    for buf in (d_gath.cpu().numpy(), h_gath.numpy()):
+        n, overflow = buf[:8].view(np.int32)
+        assert overflow == 0 and n == len(wants[0])
+        assert key(buf[hdr:].view(MATCH_DTYPE)[:n]) == key(wants[0])
+
 
 @pytest.mark.parametrize("ch", [3, 1])
 def test_match_batch_device(oracle, ctx_factory, case1, ch):
