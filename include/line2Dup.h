@@ -234,6 +234,15 @@ public:
     std::vector<std::vector<Match>> wait() const;
     void pinBuffer(const cv::Mat& frame) const;
     void unpinBuffer(const cv::Mat& frame) const;
+    /* Threading contract.  As in the reference (line2Dup.h:272-274: match() is const and keeps no state), match() and
+     * matchBatch() may be called from several host threads on ONE Detector at the same time; every call returns exactly
+     * what it would return alone.  Each concurrent caller works on its own engine context(s) ("lane": device buffers +
+     * uploaded templates, created on first need and kept); setConcurrency(n) bounds how many exist (default 4; callers
+     * beyond that wait for a free one; 1 = calls are serialised).  matchAsync()/wait() is one batch in flight per
+     * detector.  addTemplate*, read*, setDevice(s) and setConcurrency mutate the detector and must not run concurrently
+     * with anything else on it -- also as in the reference. */
+    void setConcurrency(int max_concurrent_calls);
+    struct Engine; /* opaque: the lane pool, defined in facade/line2Dup_amd.cpp */
 
 protected:
     cv::Ptr<ColorGradient> modality;
@@ -247,33 +256,13 @@ protected:
     static Detector* instance;
 
 private:
-    /* device side: one sbm_ctx per device (ctx_ = the first), templates re-uploaded when class_templates changed */
-    mutable sbm_ctx* ctx_;
-    mutable std::vector<sbm_ctx*> ctxs_;
-    mutable bool templates_dirty_;
-    mutable std::vector<std::string> uploaded_class_order_;
-    mutable std::vector<int32_t> uploaded_class_of_; /* class index of every uploaded template, upload order */
-    mutable std::vector<int32_t> selected_;   /* class selection currently active in the engine (match() caches it) */
-    mutable bool selection_valid_ = false;
-    mutable int selection_mode_ = 0;          /* 0: every context holds the whole selection; 1: sharded over the contexts */
-    mutable int selection_rows_ = 0, selection_cols_ = 0; /* geometry the shards were balanced for */
-    mutable std::vector<unsigned char> recs_;  /* match record scratch, kept between calls */
+    /* device side (facade/line2Dup_amd.cpp): a pool of LANES, each one engine context per device with the templates
+     * uploaded and its own class selection.  A match() call takes a free lane for its duration -- creating one, up to
+     * setConcurrency(), when all are busy, else waiting -- so concurrent callers never share a context. */
+    mutable Engine* eng_;
     int device_id_;
     std::vector<int> device_ids_;
-    /* batch in flight (matchAsync): frames per context, capacity, result scratch */
-    struct AsyncState {
-        bool active = false;
-        std::vector<int> first, count; /* frame range of every context */
-        int64_t cap = 0;
-        size_t n_frames = 0;
-    };
-    mutable AsyncState async_;
-    void ensureContext() const;
-    void uploadTemplates() const;
     void dropContext();
-    /* returns false when the class selection is empty (nothing to match) */
-    bool prepare(const std::vector<std::string>& class_ids, int rows, int cols, bool sharded) const;
-    std::vector<Match> toMatches(const void* recs, int64_t n) const;
 };
 
 } // namespace line2Dup

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <thread>
 #include <vector>
 
 #include "../../include/line2Dup.h"
@@ -276,6 +277,65 @@ int main(int argc, char** argv)
                 printf("%d %d %u %s %d\n", m.x, m.y, bits, m.class_id.c_str(), m.template_id);
             }
             return 0;
+        }
+        if (mode == "threads") {
+            // Concurrent callers on ONE detector (the reference's match() is const and keeps no state, line2Dup.h:272-274):
+            // n_threads host threads x n_calls match() calls each, two frame sizes interleaved, a batch thrown in now and then;
+            // every list must equal the one the same call returns alone.  demo threads <fmt> <class> <image> <threshold>
+            // <num_features> <n_threads> <n_calls> <pad> [max_lanes]
+            if (argc < 10) return usage();
+            const std::string fmt = argv[2], class_id = argv[3], path = argv[4];
+            const float threshold = (float)atof(argv[5]);
+            const int num_features = atoi(argv[6]), n_threads = atoi(argv[7]), n_calls = atoi(argv[8]), pad = atoi(argv[9]);
+            line2Dup::Detector detector(num_features, {4, 8});
+            if (argc > 10) detector.setConcurrency(atoi(argv[10]));
+            std::vector<std::string> ids{class_id};
+            detector.readClasses(ids, fmt);
+            Mat test_img = imread(path, IMREAD_UNCHANGED);
+            if (test_img.empty()) { fprintf(stderr, "cannot read %s\n", path.c_str()); return 1; }
+            Mat padded(test_img.rows + 2 * pad, test_img.cols + 2 * pad, test_img.type(), Scalar::all(0));
+            test_img.copyTo(padded(Rect(pad, pad, test_img.cols, test_img.rows)));
+            // two geometries: the padded frame, and the same with 64 rows / 32 columns less
+            std::vector<Mat> frames;
+            frames.push_back(padded(Rect(0, 0, 16 * (padded.cols / 16), 16 * (padded.rows / 16))).clone());
+            frames.push_back(padded(Rect(0, 0, 16 * (padded.cols / 16) - 32, 16 * (padded.rows / 16) - 64)).clone());
+            auto same = [](const std::vector<line2Dup::Match>& a, const std::vector<line2Dup::Match>& b) {
+                if (a.size() != b.size()) return false;
+                for (size_t i = 0; i < a.size(); ++i)
+                    if (!(a[i] == b[i]) || a[i].template_id != b[i].template_id) return false;
+                return true;
+            };
+            std::vector<std::vector<line2Dup::Match>> alone;
+            for (const Mat& f : frames) alone.push_back(detector.match(f, threshold, ids));
+            std::vector<int> bad((size_t)n_threads, 0);
+            std::vector<std::string> errs((size_t)n_threads);
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_threads; ++t)
+                th.emplace_back([&, t]() {
+                    try {
+                        for (int i = 0; i < n_calls; ++i) {
+                            const size_t k = (size_t)((t + i) & 1);
+                            if (i % 10 == 9) { // a batch of three frames of one size
+                                const auto b = detector.matchBatch({frames[k], frames[k], frames[k]}, threshold, ids);
+                                for (const auto& l : b)
+                                    if (!same(l, alone[k])) ++bad[(size_t)t];
+                            } else if (!same(detector.match(frames[k], threshold, ids), alone[k])) {
+                                ++bad[(size_t)t];
+                            }
+                        }
+                    } catch (const std::exception& e) {
+                        errs[(size_t)t] = e.what();
+                        ++bad[(size_t)t];
+                    }
+                });
+            for (auto& t : th) t.join();
+            int n_bad = 0;
+            for (int t = 0; t < n_threads; ++t) {
+                n_bad += bad[(size_t)t];
+                if (!errs[(size_t)t].empty()) fprintf(stderr, "thread %d: %s\n", t, errs[(size_t)t].c_str());
+            }
+            printf("threads %d calls %d matches %zu %zu different %d\n", n_threads, n_calls, alone[0].size(), alone[1].size(), n_bad);
+            return n_bad ? 2 : 0;
         }
         if (mode == "instance") {
             if (argc < 5) return usage();

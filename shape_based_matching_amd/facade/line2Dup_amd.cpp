@@ -10,8 +10,11 @@
 
 #include <algorithm>
 #include <climits>
+#include <condition_variable>
 #include <cstring>
 #include <iostream>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <thread>
@@ -279,20 +282,71 @@ void ColorGradient::write(FileStorage& fs) const
 // ---- Detector (line2Dup.cpp:1054-1599) --------------------------------------------
 Detector* Detector::instance = nullptr;
 
-Detector::Detector() : modality(makePtr<ColorGradient>()), pyramid_levels(2), T_at_level({4, 8}), ctx_(nullptr), templates_dirty_(true), device_id_(0) {}
+// ---- device side: a pool of lanes -------------------------------------------------------------------------------
+// The reference's match() is const and keeps no state (line2Dup.h:272-274): two threads may call it on one Detector.
+// Here a call needs an engine context (device buffers sized for the frame, uploaded templates, a stream), which is not
+// thread-safe.  So the Detector keeps a pool of LANES -- a lane = one context per device + what was uploaded / selected
+// on them -- and every call takes a free lane for its duration: concurrent callers never share a context, a single
+// caller only ever uses lane 0.
+struct Detector::Engine {
+    struct Flat { // the TemplatesMap flattened for sbm_upload_templates, rebuilt when class_templates changed
+        std::vector<sbm_template_level> levels;
+        std::vector<sbm_feature> feats;
+        std::vector<int32_t> cls, tid;
+        std::vector<std::string> class_order; // class index -> id (map order = the order match() walks the classes, :1127-1129)
+    };
+    struct Lane {
+        std::vector<sbm_ctx*> ctxs; // one per device
+        std::shared_ptr<const Flat> uploaded;
+        std::vector<int32_t> selected; // class selection currently active in the engine
+        bool selection_valid = false;
+        int selection_mode = 0; // 0: every context holds the whole selection; 1: sharded over the contexts
+        int selection_rows = 0, selection_cols = 0; // geometry the shards were balanced for
+        std::vector<unsigned char> recs; // match record scratch, kept between calls
+        bool busy = false;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::unique_ptr<Lane>> lanes;
+    int max_lanes = 4;
+    std::shared_ptr<const Flat> flat; // null = class_templates changed since the last flattening
+    std::map<const void*, std::pair<int, sbm_ctx*>> pins; // pinBuffer: buffer -> (lane, context it is registered with)
+    struct Async { // batch in flight (matchAsync): its lane, frames per context, capacity, what a retry needs
+        bool active = false;
+        int lane = -1;
+        std::vector<int> first, count;
+        int64_t cap = 0;
+        size_t n_frames = 0;
+        std::vector<Mat> sources;
+        Mat mask8;
+        float threshold = 0.f;
+        std::shared_ptr<const Flat> flat;
+    } async;
+};
+
+namespace {
+struct LaneLease { // releases the lane when the call ends, also by exception
+    line2Dup::Detector::Engine* e;
+    int idx;
+    ~LaneLease();
+};
+} // namespace
+
+Detector::Detector() : modality(makePtr<ColorGradient>()), pyramid_levels(2), T_at_level({4, 8}), eng_(new Engine), device_id_(0) {}
 Detector::Detector(std::vector<int> T)
-    : modality(makePtr<ColorGradient>()), pyramid_levels((int)T.size()), T_at_level(T), ctx_(nullptr), templates_dirty_(true), device_id_(0)
+    : modality(makePtr<ColorGradient>()), pyramid_levels((int)T.size()), T_at_level(T), eng_(new Engine), device_id_(0)
 {
 }
 Detector::Detector(int num_features, std::vector<int> T, float weak_thresh, float strong_thresh)
     : modality(makePtr<ColorGradient>(weak_thresh, (size_t)num_features, strong_thresh)), pyramid_levels((int)T.size()), T_at_level(T),
-      ctx_(nullptr), templates_dirty_(true), device_id_(0)
+      eng_(new Engine), device_id_(0)
 {
 }
 Detector::Detector(const Detector& o)
     : modality(makePtr<ColorGradient>(*o.modality)), pyramid_levels(o.pyramid_levels), T_at_level(o.T_at_level),
-      class_templates(o.class_templates), ctx_(nullptr), templates_dirty_(true), device_id_(o.device_id_), device_ids_(o.device_ids_)
+      class_templates(o.class_templates), eng_(new Engine), device_id_(o.device_id_), device_ids_(o.device_ids_)
 {
+    eng_->max_lanes = o.eng_->max_lanes;
 }
 Detector& Detector::operator=(const Detector& o)
 {
@@ -304,19 +358,28 @@ Detector& Detector::operator=(const Detector& o)
         class_templates = o.class_templates;
         device_id_ = o.device_id_;
         device_ids_ = o.device_ids_;
+        eng_->max_lanes = o.eng_->max_lanes;
     }
     return *this;
 }
-Detector::~Detector() { dropContext(); }
+Detector::~Detector()
+{
+    dropContext();
+    delete eng_;
+}
 
+// mutators only (not thread-safe against running calls, as in the reference)
 void Detector::dropContext()
 {
-    selection_valid_ = false;
-    async_.active = false;
-    for (sbm_ctx* c : ctxs_) sbm_destroy(c);
-    ctxs_.clear();
-    ctx_ = nullptr;
-    templates_dirty_ = true;
+    Engine& e = *eng_;
+    std::lock_guard<std::mutex> lock(e.mu);
+    e.async = Engine::Async();
+    for (auto& kv : e.pins) (void)sbm_unpin_host_buffer(kv.second.second, kv.first);
+    e.pins.clear();
+    for (auto& l : e.lanes)
+        for (sbm_ctx* c : l->ctxs) sbm_destroy(c);
+    e.lanes.clear();
+    e.flat.reset();
 }
 
 void Detector::setDevice(int device_id)
@@ -334,225 +397,341 @@ void Detector::setDevices(const std::vector<int>& device_ids)
     device_id_ = device_ids[0];
 }
 
-void Detector::ensureContext() const
+void Detector::setConcurrency(int n)
 {
-    if (ctx_) return;
-    CV_Assert(pyramid_levels >= 1 && pyramid_levels <= SBM_MAX_LEVELS && (int)T_at_level.size() >= pyramid_levels);
-    const std::vector<int> devs = device_ids_.empty() ? std::vector<int>{device_id_} : device_ids_;
-    for (int d : devs) {
-        sbm_config cfg;
-        memset(&cfg, 0, sizeof cfg);
-        cfg.n_levels = pyramid_levels;
-        for (int l = 0; l < pyramid_levels; ++l) cfg.T[l] = T_at_level[l];
-        cfg.weak_threshold = modality->weak_threshold;
-        cfg.device_id = d;
-        cfg.max_candidates = 0;
-        sbm_ctx* c = nullptr;
-        check(sbm_create(&cfg, &c), "sbm_create");
-        ctxs_.push_back(c);
-    }
-    ctx_ = ctxs_[0];
-    templates_dirty_ = true;
+    CV_Assert(n >= 1);
+    std::lock_guard<std::mutex> lock(eng_->mu);
+    eng_->max_lanes = n; // lanes beyond n that already exist stay (their memory is the price already paid); no new ones
 }
 
-// flatten the TemplatesMap (map order = the order match() walks the classes, :1127-1129)
-void Detector::uploadTemplates() const
+LaneLease::~LaneLease()
 {
-    std::vector<sbm_template_level> levels;
-    std::vector<sbm_feature> feats;
-    std::vector<int32_t> cls, tid;
-    uploaded_class_order_.clear();
-    selection_valid_ = false; // sbm_upload_templates selects every class again
-    for (const auto& kv : class_templates) {
-        const int ci = (int)uploaded_class_order_.size();
-        uploaded_class_order_.push_back(kv.first);
-        for (size_t t = 0; t < kv.second.size(); ++t) {
-            const TemplatePyramid& tp = kv.second[t];
-            CV_Assert((int)tp.size() == pyramid_levels);
-            for (const Template& tm : tp) {
-                if (tm.features.size() >= 8192) CV_Error(Error::StsBadArg, "feature size too large"); // :1195
-                sbm_template_level lv;
-                lv.width = tm.width;
-                lv.height = tm.height;
-                lv.tl_x = tm.tl_x;
-                lv.tl_y = tm.tl_y;
-                lv.pyramid_level = tm.pyramid_level;
-                lv.n_features = (int32_t)tm.features.size();
-                lv.feature_offset = (int64_t)feats.size();
-                for (const Feature& f : tm.features) feats.push_back(sbm_feature{f.x, f.y, f.label});
-                levels.push_back(lv);
+    {
+        std::lock_guard<std::mutex> lock(e->mu);
+        e->lanes[(size_t)idx]->busy = false;
+    }
+    e->cv.notify_all();
+}
+
+namespace {
+
+// take a free lane (want < 0: any; else that one), creating an empty one while the pool may grow, else wait
+int acquire_lane(line2Dup::Detector::Engine& e, int want = -1)
+{
+    std::unique_lock<std::mutex> lock(e.mu);
+    for (;;) {
+        if (want >= 0) {
+            if ((size_t)want < e.lanes.size() && !e.lanes[(size_t)want]->busy) {
+                e.lanes[(size_t)want]->busy = true;
+                return want;
             }
-            cls.push_back(ci);
-            tid.push_back((int32_t)t);
+        } else {
+            for (size_t i = 0; i < e.lanes.size(); ++i)
+                if (!e.lanes[i]->busy) {
+                    e.lanes[i]->busy = true;
+                    return (int)i;
+                }
+            if ((int)e.lanes.size() < e.max_lanes) {
+                e.lanes.emplace_back(new line2Dup::Detector::Engine::Lane);
+                e.lanes.back()->busy = true;
+                return (int)e.lanes.size() - 1;
+            }
         }
+        e.cv.wait(lock);
     }
-    for (sbm_ctx* c : ctxs_)
-        check(sbm_upload_templates(c, (int32_t)cls.size(), levels.data(), feats.data(), (int64_t)feats.size(), cls.data(), tid.data()),
-              "sbm_upload_templates");
-    uploaded_class_of_ = cls;
-    templates_dirty_ = false;
 }
 
-// Context, templates and class selection for a call.  sharded: the selected templates are divided over the contexts
-// (match() with several devices); else every context holds the whole selection (one device, or matchBatch, which deals
-// frames).  The engine's selection calls synchronise the device, so they are issued only when something changed.
-bool Detector::prepare(const std::vector<std::string>& class_ids, int rows, int cols, bool sharded) const
+} // namespace
+
+// Contexts, templates and class selection of lane `li` (held by the caller) for a call.  sharded: the selected templates
+// are divided over the lane's contexts (match() with several devices); else every context holds the whole selection (one
+// device, or matchBatch, which deals frames).  The engine's selection calls synchronise the device, so they are issued
+// only when something changed.  Returns the flattening the lane now holds, or null when the selection is empty.
+static std::shared_ptr<const Detector::Engine::Flat> prepare_lane(const Detector& det, Detector::Engine& e, int li, const std::vector<int>& devs,
+                                                                  const std::map<std::string, std::vector<std::vector<Template>>>& class_templates,
+                                                                  int pyramid_levels, const std::vector<int>& T_at_level, float weak_threshold,
+                                                                  const std::vector<std::string>& class_ids, int rows, int cols, bool sharded)
 {
-    ensureContext();
-    if (templates_dirty_) uploadTemplates();
-    if (class_templates.empty()) return false;
+    (void)det;
+    typedef Detector::Engine::Flat Flat;
+    Detector::Engine::Lane& lane = *e.lanes[(size_t)li];
+    if (lane.ctxs.empty()) {
+        CV_Assert(pyramid_levels >= 1 && pyramid_levels <= SBM_MAX_LEVELS && (int)T_at_level.size() >= pyramid_levels);
+        for (int d : devs) {
+            sbm_config cfg;
+            memset(&cfg, 0, sizeof cfg);
+            cfg.n_levels = pyramid_levels;
+            for (int l = 0; l < pyramid_levels; ++l) cfg.T[l] = T_at_level[l];
+            cfg.weak_threshold = weak_threshold;
+            cfg.device_id = d;
+            cfg.max_candidates = 0;
+            sbm_ctx* c = nullptr;
+            check(sbm_create(&cfg, &c), "sbm_create");
+            lane.ctxs.push_back(c);
+        }
+        lane.uploaded.reset();
+    }
+    // one flattening of the TemplatesMap per change, shared by the lanes
+    std::shared_ptr<const Flat> flat;
+    {
+        std::lock_guard<std::mutex> lock(e.mu);
+        if (!e.flat) {
+            std::shared_ptr<Flat> f(new Flat);
+            for (const auto& kv : class_templates) {
+                const int ci = (int)f->class_order.size();
+                f->class_order.push_back(kv.first);
+                for (size_t t = 0; t < kv.second.size(); ++t) {
+                    const std::vector<Template>& tp = kv.second[t];
+                    CV_Assert((int)tp.size() == pyramid_levels);
+                    for (const Template& tm : tp) {
+                        if (tm.features.size() >= 8192) CV_Error(Error::StsBadArg, "feature size too large"); // :1195
+                        sbm_template_level lv;
+                        lv.width = tm.width;
+                        lv.height = tm.height;
+                        lv.tl_x = tm.tl_x;
+                        lv.tl_y = tm.tl_y;
+                        lv.pyramid_level = tm.pyramid_level;
+                        lv.n_features = (int32_t)tm.features.size();
+                        lv.feature_offset = (int64_t)f->feats.size();
+                        for (const Feature& ft : tm.features) f->feats.push_back(sbm_feature{ft.x, ft.y, ft.label});
+                        f->levels.push_back(lv);
+                    }
+                    f->cls.push_back(ci);
+                    f->tid.push_back((int32_t)t);
+                }
+            }
+            e.flat = f;
+        }
+        flat = e.flat;
+    }
+    if (lane.uploaded != flat) {
+        for (sbm_ctx* c : lane.ctxs)
+            check(sbm_upload_templates(c, (int32_t)flat->cls.size(), flat->levels.data(), flat->feats.data(), (int64_t)flat->feats.size(),
+                                       flat->cls.data(), flat->tid.data()),
+                  "sbm_upload_templates");
+        lane.uploaded = flat;
+        lane.selection_valid = false; // sbm_upload_templates selects every class again
+    }
+    if (flat->cls.empty()) return nullptr;
     std::vector<int32_t> sel;
     if (!class_ids.empty()) { // unknown ids are skipped silently (:1136-1138)
         for (const std::string& id : class_ids) {
-            auto it = std::find(uploaded_class_order_.begin(), uploaded_class_order_.end(), id);
-            if (it != uploaded_class_order_.end()) sel.push_back((int32_t)(it - uploaded_class_order_.begin()));
+            auto it = std::find(flat->class_order.begin(), flat->class_order.end(), id);
+            if (it != flat->class_order.end()) sel.push_back((int32_t)(it - flat->class_order.begin()));
         }
-        if (sel.empty()) return false;
+        if (sel.empty()) return nullptr;
     }
-    const int mode = sharded && ctxs_.size() > 1 ? 1 : 0;
-    if (selection_valid_ && sel == selected_ && mode == selection_mode_ && (mode == 0 || (rows == selection_rows_ && cols == selection_cols_)))
-        return true;
+    const int mode = sharded && lane.ctxs.size() > 1 ? 1 : 0;
+    if (lane.selection_valid && sel == lane.selected && mode == lane.selection_mode &&
+        (mode == 0 || (rows == lane.selection_rows && cols == lane.selection_cols)))
+        return flat;
     if (mode == 0) {
-        for (sbm_ctx* c : ctxs_)
+        for (sbm_ctx* c : lane.ctxs)
             check(sbm_select_classes(c, sel.empty() ? nullptr : sel.data(), (int32_t)sel.size()), "sbm_select_classes");
     } else {
         // the list matchClass would walk (class_ids order, then template order, :1134-1139), cut into work-balanced pieces
         std::vector<int32_t> act;
         if (sel.empty()) {
-            act.resize(uploaded_class_of_.size());
+            act.resize(flat->cls.size());
             for (size_t t = 0; t < act.size(); ++t) act[t] = (int32_t)t;
         } else {
             for (int32_t ci : sel)
-                for (size_t t = 0; t < uploaded_class_of_.size(); ++t)
-                    if (uploaded_class_of_[t] == ci) act.push_back((int32_t)t);
+                for (size_t t = 0; t < flat->cls.size(); ++t)
+                    if (flat->cls[t] == ci) act.push_back((int32_t)t);
         }
-        const int D = (int)ctxs_.size();
+        const int D = (int)lane.ctxs.size();
         std::vector<int32_t> first(D), count(D);
-        check(sbm_partition_templates(ctx_, rows, cols, act.data(), (int32_t)act.size(), D, first.data(), count.data()), "sbm_partition_templates");
-        for (int d = 0; d < D; ++d) check(sbm_select_templates(ctxs_[d], act.data() + first[d], count[d]), "sbm_select_templates");
+        check(sbm_partition_templates(lane.ctxs[0], rows, cols, act.data(), (int32_t)act.size(), D, first.data(), count.data()),
+              "sbm_partition_templates");
+        for (int d = 0; d < D; ++d) check(sbm_select_templates(lane.ctxs[d], act.data() + first[d], count[d]), "sbm_select_templates");
     }
-    selected_ = sel;
-    selection_mode_ = mode;
-    selection_rows_ = rows;
-    selection_cols_ = cols;
-    selection_valid_ = true;
-    return true;
+    lane.selected = sel;
+    lane.selection_mode = mode;
+    lane.selection_rows = rows;
+    lane.selection_cols = cols;
+    lane.selection_valid = true;
+    return flat;
 }
 
 // epilogue (:1142-1145): canonical sort, exact-duplicate removal, then the reference's own adjacent std::unique (its
 // operator== ignores template_id)
-std::vector<Match> Detector::toMatches(const void* recs_in, int64_t n) const
+static std::vector<Match> to_matches(const Detector::Engine::Flat& flat, const void* recs_in, int64_t n)
 {
     std::vector<sbm_match_rec> recs((const sbm_match_rec*)recs_in, (const sbm_match_rec*)recs_in + n);
     n = sbm_canonicalize(recs.data(), n);
     std::vector<Match> matches;
     matches.reserve((size_t)n);
     for (int64_t i = 0; i < n; ++i)
-        matches.push_back(Match(recs[i].x, recs[i].y, recs[i].similarity, uploaded_class_order_[recs[i].class_idx], recs[i].template_id));
+        matches.push_back(Match(recs[i].x, recs[i].y, recs[i].similarity, flat.class_order[(size_t)recs[i].class_idx], recs[i].template_id));
     matches.erase(std::unique(matches.begin(), matches.end()), matches.end());
     return matches;
+}
+
+// one frame on the lane's context(s); grows the lane's record scratch until the list fits
+static int64_t match_on_lane(Detector::Engine::Lane& lane, const Mat& source, const Mat& mask8, float threshold)
+{
+    if (lane.recs.size() < (size_t)4096 * sizeof(sbm_match_rec)) lane.recs.resize((size_t)4096 * sizeof(sbm_match_rec));
+    int64_t n = 0;
+    for (;;) {
+        const int64_t cap = (int64_t)(lane.recs.size() / sizeof(sbm_match_rec));
+        // several devices: one host thread and context per device, each with its shard of the templates, lists
+        // concatenated (the OpenMP team of :1166-1170); one device: the plain call
+        int rc = lane.ctxs.size() > 1
+                     ? sbm_match_sharded(lane.ctxs.data(), (int32_t)lane.ctxs.size(), source.data, source.rows, source.cols, (int)source.step,
+                                         source.channels(), mask8.empty() ? nullptr : mask8.data, threshold, (sbm_match_rec*)lane.recs.data(), cap, &n)
+                     : sbm_match(lane.ctxs[0], source.data, source.rows, source.cols, (int)source.step, source.channels(),
+                                 mask8.empty() ? nullptr : mask8.data, threshold, (sbm_match_rec*)lane.recs.data(), cap, &n);
+        if (rc == SBM_ERR_CAPACITY && n > cap) {
+            lane.recs.resize((size_t)n * sizeof(sbm_match_rec));
+            continue;
+        }
+        check(rc, "sbm_match");
+        return n;
+    }
 }
 
 std::vector<Match> Detector::match(Mat source, float threshold, const std::vector<std::string>& class_ids, const Mat mask) const
 {
     CV_Assert(mask.empty() || mask.size() == source.size()); // :1086
     CV_Assert(!source.empty() && source.depth() == CV_8U && (source.channels() == 1 || source.channels() == 3));
-    CV_Assert(!async_.active);
-    if (!prepare(class_ids, source.rows, source.cols, true)) return std::vector<Match>();
-
     Mat mask8;
     if (!mask.empty()) {
         CV_Assert(mask.type() == CV_8UC1);
         mask8 = mask.isContinuous() ? mask : mask.clone();
     }
-    if (recs_.size() < (size_t)4096 * sizeof(sbm_match_rec)) recs_.resize((size_t)4096 * sizeof(sbm_match_rec));
-    int64_t n = 0;
-    for (;;) {
-        const int64_t cap = (int64_t)(recs_.size() / sizeof(sbm_match_rec));
-        // several devices: one host thread and context per device, each with its shard of the templates, lists
-        // concatenated (the OpenMP team of :1166-1170); one device: the plain call
-        int rc = ctxs_.size() > 1
-                     ? sbm_match_sharded(ctxs_.data(), (int32_t)ctxs_.size(), source.data, source.rows, source.cols, (int)source.step,
-                                         source.channels(), mask8.empty() ? nullptr : mask8.data, threshold, (sbm_match_rec*)recs_.data(), cap, &n)
-                     : sbm_match(ctx_, source.data, source.rows, source.cols, (int)source.step, source.channels(),
-                                 mask8.empty() ? nullptr : mask8.data, threshold, (sbm_match_rec*)recs_.data(), cap, &n);
-        if (rc == SBM_ERR_CAPACITY && n > cap) {
-            recs_.resize((size_t)n * sizeof(sbm_match_rec));
-            continue;
-        }
-        check(rc, "sbm_match");
-        break;
-    }
-    return toMatches(recs_.data(), n);
+    Engine& e = *eng_;
+    LaneLease lease{&e, acquire_lane(e)};
+    const std::vector<int> devs = device_ids_.empty() ? std::vector<int>{device_id_} : device_ids_;
+    const std::shared_ptr<const Engine::Flat> flat = prepare_lane(*this, e, lease.idx, devs, class_templates, pyramid_levels, T_at_level,
+                                                                  modality->weak_threshold, class_ids, source.rows, source.cols, true);
+    if (!flat) return std::vector<Match>();
+    Engine::Lane& lane = *e.lanes[(size_t)lease.idx];
+    const int64_t n = match_on_lane(lane, source, mask8, threshold);
+    return to_matches(*flat, lane.recs.data(), n);
 }
 
 // ---- throughput path: batches of frames from host memory, uploads overlapped with the kernels ----------------------
 void Detector::matchAsync(const std::vector<Mat>& sources, float threshold, const std::vector<std::string>& class_ids, const Mat mask) const
 {
-    CV_Assert(!async_.active && !sources.empty());
+    CV_Assert(!sources.empty());
     const Mat& s0 = sources[0];
     for (const Mat& m : sources) {
         CV_Assert(!m.empty() && m.depth() == CV_8U && (m.channels() == 1 || m.channels() == 3));
         CV_Assert(m.rows == s0.rows && m.cols == s0.cols && m.channels() == s0.channels() && m.step == s0.step);
     }
     CV_Assert(mask.empty() || (mask.size() == s0.size() && mask.type() == CV_8UC1));
-    async_ = AsyncState();
-    async_.n_frames = sources.size();
-    if (!prepare(class_ids, s0.rows, s0.cols, false)) { // nothing selected: wait() returns empty lists
-        async_.active = true;
-        async_.cap = 0;
-        return;
+    Engine& e = *eng_;
+    {
+        std::lock_guard<std::mutex> lock(e.mu);
+        CV_Assert(!e.async.active); // one batch in flight per detector
+        e.async = Engine::Async();
+        e.async.active = true; // claimed; filled in below by this thread only
     }
-    Mat mask8;
-    if (!mask.empty()) mask8 = mask.isContinuous() ? mask : mask.clone();
-    // frames dealt over the devices in contiguous groups (frames are independent: Detector::match keeps no state)
-    const int D = (int)ctxs_.size(), n = (int)sources.size();
-    async_.cap = 1024;
-    for (int d = 0; d < D; ++d) {
-        async_.first.push_back((int)((int64_t)n * d / D));
-        async_.count.push_back((int)((int64_t)n * (d + 1) / D) - async_.first.back());
-    }
-    for (int d = 0; d < D; ++d) {
-        if (!async_.count[d]) continue;
-        std::vector<const uint8_t*> ptrs;
-        for (int f = 0; f < async_.count[d]; ++f) ptrs.push_back(sources[async_.first[d] + f].data);
-        const int rc = sbm_match_batch_host_begin(ctxs_[d], ptrs.data(), (int32_t)ptrs.size(), s0.rows, s0.cols, (int)s0.step, s0.channels(),
-                                                  mask8.empty() ? nullptr : mask8.data, threshold, async_.cap, 0);
-        if (rc) {
-            const std::string msg = sbm_last_error();
-            for (int e = 0; e < d; ++e) { // drain what was started
-                std::vector<sbm_match_rec> tmp((size_t)async_.count[e] * async_.cap);
-                std::vector<int32_t> cnt((size_t)async_.count[e] * 2);
-                if (async_.count[e]) (void)sbm_match_batch_host_end(ctxs_[e], tmp.data(), cnt.data());
-            }
-            CV_Error(rc == SBM_ERR_INVALID ? Error::StsBadArg : Error::StsError, "sbm_match_batch_host_begin: " + msg);
+    Engine::Async& as = e.async;
+    const int li = acquire_lane(e);
+    as.lane = li;
+    auto give_up = [&]() { // nothing in flight after all: free the lane and the claim
+        LaneLease drop{&e, li};
+        std::lock_guard<std::mutex> lock(e.mu);
+        as.active = false;
+    };
+    try {
+        as.n_frames = sources.size();
+        as.threshold = threshold;
+        const std::vector<int> devs = device_ids_.empty() ? std::vector<int>{device_id_} : device_ids_;
+        as.flat = prepare_lane(*this, e, li, devs, class_templates, pyramid_levels, T_at_level, modality->weak_threshold, class_ids, s0.rows,
+                               s0.cols, false);
+        if (!as.flat) { // nothing selected: wait() returns empty lists
+            as.cap = 0;
+            return;
         }
+        Engine::Lane& lane = *e.lanes[(size_t)li];
+        // the frames (Mat headers: the pixels are the caller's and must stay unchanged until wait()) and the mask (a copy
+        // when it is not continuous) are kept until wait(): the uploads enqueued below read them after this call returns
+        as.sources = sources;
+        if (!mask.empty()) as.mask8 = mask.isContinuous() ? mask : mask.clone();
+        // frames dealt over the devices in contiguous groups (frames are independent: Detector::match keeps no state)
+        const int D = (int)lane.ctxs.size(), n = (int)sources.size();
+        as.cap = 1024;
+        for (int d = 0; d < D; ++d) {
+            as.first.push_back((int)((int64_t)n * d / D));
+            as.count.push_back((int)((int64_t)n * (d + 1) / D) - as.first.back());
+        }
+        for (int d = 0; d < D; ++d) {
+            if (!as.count[d]) continue;
+            std::vector<const uint8_t*> ptrs;
+            for (int f = 0; f < as.count[d]; ++f) ptrs.push_back(sources[as.first[d] + f].data);
+            const int rc = sbm_match_batch_host_begin(lane.ctxs[d], ptrs.data(), (int32_t)ptrs.size(), s0.rows, s0.cols, (int)s0.step, s0.channels(),
+                                                      as.mask8.empty() ? nullptr : as.mask8.data, threshold, as.cap, 0);
+            if (rc) {
+                const std::string msg = sbm_last_error();
+                for (int k = 0; k < d; ++k) { // drain what was started
+                    std::vector<sbm_match_rec> tmp((size_t)as.count[k] * as.cap);
+                    std::vector<int32_t> cnt((size_t)as.count[k] * 2);
+                    if (as.count[k]) (void)sbm_match_batch_host_end(lane.ctxs[k], tmp.data(), cnt.data());
+                }
+                CV_Error(rc == SBM_ERR_INVALID ? Error::StsBadArg : Error::StsError, "sbm_match_batch_host_begin: " + msg);
+            }
+        }
+    } catch (...) {
+        give_up();
+        throw;
     }
-    async_.active = true;
 }
 
 std::vector<std::vector<Match>> Detector::wait() const
 {
-    CV_Assert(async_.active);
-    async_.active = false;
-    std::vector<std::vector<Match>> out(async_.n_frames);
-    if (async_.cap == 0) return out;
+    Engine& e = *eng_;
+    Engine::Async& as = e.async;
+    {
+        std::lock_guard<std::mutex> lock(e.mu);
+        CV_Assert(as.active && as.lane >= 0);
+    }
+    LaneLease lease{&e, as.lane}; // the lane matchAsync took is released when this call ends
+    struct Done {
+        Detector::Engine& e;
+        ~Done()
+        {
+            std::lock_guard<std::mutex> lock(e.mu);
+            e.async = Detector::Engine::Async();
+        }
+    } done{e};
+    std::vector<std::vector<Match>> out(as.n_frames);
+    if (as.cap == 0) return out;
+    Engine::Lane& lane = *e.lanes[(size_t)as.lane];
     int bad = 0;
     std::string msg;
-    for (size_t d = 0; d < ctxs_.size(); ++d) {
-        const int nf = async_.count[d];
+    std::vector<size_t> redo; // frames whose list did not fit the batch's per-frame capacity
+    for (size_t d = 0; d < lane.ctxs.size(); ++d) {
+        const int nf = as.count[d];
         if (!nf) continue;
-        std::vector<sbm_match_rec> recs((size_t)nf * async_.cap);
+        std::vector<sbm_match_rec> recs((size_t)nf * as.cap);
         std::vector<int32_t> cnt((size_t)nf * 2);
-        const int rc = sbm_match_batch_host_end(ctxs_[d], recs.data(), cnt.data());
-        if (rc && !bad) {
+        const int rc = sbm_match_batch_host_end(lane.ctxs[d], recs.data(), cnt.data());
+        if (rc && rc != SBM_ERR_CAPACITY && !bad) {
             bad = rc;
             msg = sbm_last_error();
         }
-        if (rc) continue;
-        for (int f = 0; f < nf; ++f) out[async_.first[d] + f] = toMatches(recs.data() + (size_t)f * async_.cap, cnt[2 * f]);
+        if (rc && rc != SBM_ERR_CAPACITY) continue;
+        // SBM_ERR_CAPACITY: some frame of this context produced more raw records than the per-frame capacity of the batch
+        // (its count says how many, or its overflow flag is set).  The other frames' lists are complete: keep them, and
+        // run the affected frames again one at a time, where match() grows its buffer -- the promise is
+        // matchBatch(frames)[f] == match(frames[f]) whatever the lists' sizes.
+        for (int f = 0; f < nf; ++f) {
+            if (cnt[2 * f] < 0 || cnt[2 * f] > as.cap || cnt[2 * f + 1] != 0) redo.push_back((size_t)(as.first[d] + f));
+            else out[(size_t)(as.first[d] + f)] = to_matches(*as.flat, recs.data() + (size_t)f * as.cap, cnt[2 * f]);
+        }
     }
     if (bad) CV_Error(bad == SBM_ERR_INVALID ? Error::StsBadArg : Error::StsError, "sbm_match_batch_host_end: " + msg);
+    if (!redo.empty()) {
+        // the lane's selection is the batch's (whole selection on every context); one context is enough for a frame
+        Engine::Lane single;
+        single.ctxs.assign(1, lane.ctxs[0]);
+        for (size_t f : redo) {
+            const int64_t n = match_on_lane(single, as.sources[f], as.mask8, as.threshold);
+            out[f] = to_matches(*as.flat, single.recs.data(), n);
+        }
+    }
     return out;
 }
 
@@ -560,21 +739,109 @@ std::vector<std::vector<Match>> Detector::matchBatch(const std::vector<Mat>& sou
                                                      const Mat mask) const
 {
     if (sources.empty()) return std::vector<std::vector<Match>>();
-    matchAsync(sources, threshold, class_ids, mask);
-    return wait();
+    // not matchAsync + wait: several threads may run batches on one detector at once, each on a lane of its own, while
+    // matchAsync / wait is the detector's ONE batch in flight
+    const Mat& s0 = sources[0];
+    for (const Mat& m : sources) {
+        CV_Assert(!m.empty() && m.depth() == CV_8U && (m.channels() == 1 || m.channels() == 3));
+        CV_Assert(m.rows == s0.rows && m.cols == s0.cols && m.channels() == s0.channels() && m.step == s0.step);
+    }
+    CV_Assert(mask.empty() || (mask.size() == s0.size() && mask.type() == CV_8UC1));
+    Engine& e = *eng_;
+    LaneLease lease{&e, acquire_lane(e)};
+    const std::vector<int> devs = device_ids_.empty() ? std::vector<int>{device_id_} : device_ids_;
+    const std::shared_ptr<const Engine::Flat> flat = prepare_lane(*this, e, lease.idx, devs, class_templates, pyramid_levels, T_at_level,
+                                                                  modality->weak_threshold, class_ids, s0.rows, s0.cols, false);
+    std::vector<std::vector<Match>> out(sources.size());
+    if (!flat) return out;
+    Engine::Lane& lane = *e.lanes[(size_t)lease.idx];
+    Mat mask8;
+    if (!mask.empty()) mask8 = mask.isContinuous() ? mask : mask.clone();
+    const int D = (int)lane.ctxs.size(), n = (int)sources.size();
+    const int64_t cap = 1024;
+    std::vector<int> first, count;
+    for (int d = 0; d < D; ++d) {
+        first.push_back((int)((int64_t)n * d / D));
+        count.push_back((int)((int64_t)n * (d + 1) / D) - first.back());
+    }
+    int begun = 0, bad = 0;
+    std::string msg;
+    for (int d = 0; d < D && !bad; ++d, ++begun) {
+        if (!count[d]) continue;
+        std::vector<const uint8_t*> ptrs;
+        for (int f = 0; f < count[d]; ++f) ptrs.push_back(sources[first[d] + f].data);
+        const int rc = sbm_match_batch_host_begin(lane.ctxs[d], ptrs.data(), (int32_t)ptrs.size(), s0.rows, s0.cols, (int)s0.step, s0.channels(),
+                                                  mask8.empty() ? nullptr : mask8.data, threshold, cap, 0);
+        if (rc) {
+            bad = rc;
+            msg = std::string("sbm_match_batch_host_begin: ") + sbm_last_error();
+            break;
+        }
+    }
+    std::vector<size_t> redo;
+    for (int d = 0; d < begun; ++d) { // every context that began must end, whatever happened since
+        if (!count[d]) continue;
+        std::vector<sbm_match_rec> recs((size_t)count[d] * cap);
+        std::vector<int32_t> cnt((size_t)count[d] * 2);
+        const int rc = sbm_match_batch_host_end(lane.ctxs[d], recs.data(), cnt.data());
+        if (rc && rc != SBM_ERR_CAPACITY) {
+            if (!bad) {
+                bad = rc;
+                msg = std::string("sbm_match_batch_host_end: ") + sbm_last_error();
+            }
+            continue;
+        }
+        if (bad) continue;
+        for (int f = 0; f < count[d]; ++f) { // see wait(): frames whose list did not fit are matched again one at a time
+            if (cnt[2 * f] < 0 || cnt[2 * f] > cap || cnt[2 * f + 1] != 0) redo.push_back((size_t)(first[d] + f));
+            else out[(size_t)(first[d] + f)] = to_matches(*flat, recs.data() + (size_t)f * cap, cnt[2 * f]);
+        }
+    }
+    if (bad) CV_Error(bad == SBM_ERR_INVALID ? Error::StsBadArg : Error::StsError, msg);
+    if (!redo.empty()) {
+        Engine::Lane single;
+        single.ctxs.assign(1, lane.ctxs[0]);
+        for (size_t f : redo) {
+            const int64_t k = match_on_lane(single, sources[f], mask8, threshold);
+            out[f] = to_matches(*flat, single.recs.data(), k);
+        }
+    }
+    return out;
 }
 
 void Detector::pinBuffer(const Mat& frame) const
 {
     CV_Assert(!frame.empty());
-    ensureContext();
-    check(sbm_pin_host_buffer(ctx_, frame.data, (int64_t)frame.step * frame.rows), "sbm_pin_host_buffer");
+    Engine& e = *eng_;
+    LaneLease lease{&e, acquire_lane(e)};
+    Engine::Lane& lane = *e.lanes[(size_t)lease.idx];
+    if (lane.ctxs.empty()) { // a lane nobody matched on yet: give it its contexts (templates follow with the first call)
+        const std::vector<int> devs = device_ids_.empty() ? std::vector<int>{device_id_} : device_ids_;
+        prepare_lane(*this, e, lease.idx, devs, class_templates, pyramid_levels, T_at_level, modality->weak_threshold, std::vector<std::string>(), 0,
+                     0, false);
+    }
+    // page-locking is process-wide (hipHostRegister): every lane's uploads from the buffer are direct DMAs; the context
+    // only keeps the registration so that unpinBuffer can drop it
+    check(sbm_pin_host_buffer(lane.ctxs[0], frame.data, (int64_t)frame.step * frame.rows), "sbm_pin_host_buffer");
+    std::lock_guard<std::mutex> lock(e.mu);
+    e.pins[frame.data] = std::make_pair(lease.idx, lane.ctxs[0]);
 }
 
 void Detector::unpinBuffer(const Mat& frame) const
 {
-    CV_Assert(!frame.empty() && ctx_);
-    check(sbm_unpin_host_buffer(ctx_, frame.data), "sbm_unpin_host_buffer");
+    CV_Assert(!frame.empty());
+    Engine& e = *eng_;
+    int li = -1;
+    {
+        std::lock_guard<std::mutex> lock(e.mu);
+        auto it = e.pins.find(frame.data);
+        CV_Assert(it != e.pins.end());
+        li = it->second.first;
+    }
+    LaneLease lease{&e, acquire_lane(e, li)}; // the lane whose context holds the registration, once it is free
+    check(sbm_unpin_host_buffer(e.lanes[(size_t)li]->ctxs[0], frame.data), "sbm_unpin_host_buffer");
+    std::lock_guard<std::mutex> lock(e.mu);
+    e.pins.erase(frame.data);
 }
 
 int Detector::addTemplate(const Mat source, const std::string& class_id, const Mat& object_mask, float sscale, float orientation,
@@ -598,7 +865,10 @@ int Detector::addTemplate(const Mat source, const std::string& class_id, const M
     }
     crop_templates(tp);
     template_pyramids.push_back(tp);
-    templates_dirty_ = true;
+    {
+        std::lock_guard<std::mutex> lock(eng_->mu);
+        eng_->flat.reset(); // class_templates changed: the next call flattens and uploads again
+    }
     return template_id;
 }
 
@@ -634,7 +904,10 @@ int Detector::addTemplate_rotate(const std::string& class_id, int zero_id, float
     }
     crop_templates(tp);
     template_pyramids.push_back(tp);
-    templates_dirty_ = true;
+    {
+        std::lock_guard<std::mutex> lock(eng_->mu);
+        eng_->flat.reset(); // class_templates changed: the next call flattens and uploads again
+    }
     return template_id;
 }
 
@@ -703,7 +976,10 @@ std::string Detector::readClass(const FileNode& fn, const std::string& class_id_
         for (FileNodeIterator jt = templates_fn.begin(); jt != templates_fn.end(); ++jt) tps[template_id][idx++].read(*jt);
     }
     class_templates[class_id] = tps;
-    templates_dirty_ = true;
+    {
+        std::lock_guard<std::mutex> lock(eng_->mu);
+        eng_->flat.reset(); // class_templates changed: the next call flattens and uploads again
+    }
     return class_id;
 }
 

@@ -232,3 +232,53 @@ def test_facade_batch_async_and_devices(tmp_path, oracle, case1):
                 continue
             keep.append(k + (int(m["template_id"]),))
         assert got == keep and len(got) > 0
+
+
+def test_facade_concurrent_callers_on_one_detector(tmp_path, case1):
+    """Round 4: Detector::match() const is re-entrant, as the reference's (line2Dup.h:272-274, line2Dup.cpp:1078-1150 keep
+    no state): 4 host threads x 50 calls on ONE detector, two frame sizes interleaved, a matchBatch every tenth call; every
+    list equals the one the call returns alone.  Once with a lane per thread, once with 2 lanes (callers wait), once with 1
+    (serialised)."""
+    ts = case1["templates"].subset(range(300, 361, 3))
+    ts.class_ids = ["test"]
+    ts.template_id = np.arange(ts.n_templates, dtype=np.int32)
+    fmt = str(tmp_path / "%s_templ.yaml")
+    write_class_yaml(ts, fmt % "test")
+    img_path = str(tmp_path / "test.ppm")
+    write_ppm(img_path, case1["test"])
+    for lanes in ("4", "2", "1"):
+        r = subprocess.run([DEMO, "threads", fmt, "test", img_path, "88", "128", "4", "50", "60", lanes], capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, (lanes, r.stdout, r.stderr)
+        head = r.stdout.strip().splitlines()[-1].split()
+        # "threads 4 calls 50 matches <n0> <n1> different 0"
+        assert head[:5] == ["threads", "4", "calls", "50", "matches"] and head[7:] == ["different", "0"], r.stdout
+        assert int(head[5]) > 0 and int(head[6]) > 0  # both geometries find the object
+
+
+def test_facade_match_batch_lists_longer_than_the_batch_capacity(tmp_path, oracle, case1):
+    """matchBatch() promises lists[f] == match(frames[f]); a frame whose RAW (pre-dedup) record count exceeds
+    the batch's per-frame capacity of 1024 must be matched again with a larger buffer, not turned into an exception"""
+    ts = case1["templates"]
+    fmt = str(tmp_path / "%s_templ.yaml")
+    write_class_yaml(ts, fmt % "test")
+    img_path = str(tmp_path / "test.ppm")
+    write_ppm(img_path, case1["test"])
+    img = case1["test"]
+    p = synth.embed(img, img.shape[0] + 200, img.shape[1] + 200, 100, 100)
+    frame = np.ascontiguousarray(p[: p.shape[0] // 16 * 16, : p.shape[1] // 16 * 16])
+    pyr = oracle.Pyramid.build(frame, [4, 8], 30.0)
+    thr = None
+    for t in (65.0, 60.0):
+        raw = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, t, n_threads=min(16, os.cpu_count() or 1))
+        if len(raw) > 1100:
+            thr = t
+            break
+    pyr.free()
+    assert thr is not None, "no threshold gave more than 1024 raw records"
+    r = subprocess.run([DEMO, "batch", fmt, "test", img_path, str(thr), "128", "5", "100", "0,0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    head = r.stdout.strip().splitlines()[0].split()
+    flags = dict(zip(head[1::2], head[2::2]))
+    for k in ("batch_same", "async_same", "devices_same", "devices_batch_same"):
+        assert flags[k] == "1", (k, head)
