@@ -468,9 +468,9 @@ def main():
             raise SystemExit(f"bench.py rank {rank} of {world}: the library's RCCL communicator could not be set up on every rank"
                              + (f" (here: {errs[0]})" if errs else ""))
         n_ranks_seen = ctx.comm_count()  # as RCCL reports it
-    if wl.stage == "match" and not os.environ.get("SBM_BENCH_LATENCY_SIZING"):
-        for sl in slots:  # the slots' batches are in flight together: size the launches for throughput
-            sl.ctx.set_pipeline_depth(len(slots))
+    if not os.environ.get("SBM_BENCH_LATENCY_SIZING"):
+        for sl in slots:  # the slots' batches are in flight together: size the launches for throughput (and, with >= 2, let
+            sl.ctx.set_pipeline_depth(len(slots))  # the library replay captured graphs: its default, sbm_set_graph_mode)
     torch.cuda.synchronize()
     step_no = [0]
     # The steps read their frames from a RING of distinct device buffers (same contents): a stream of frames arrives from
@@ -525,13 +525,21 @@ def main():
         step_no[0] += 1
 
     def probe(n=40):
-        return timed(2 * len(active[0]), n) / n * 1e6
+        # warm-up: every (slot, input buffer) pair once -- in graph mode each pair is a capture of its own, which must not
+        # fall into the timed steps
+        return timed(max(2, len(ring)) * len(active[0]), n) / n * 1e6
 
     launch = {"path": "stream launches", "slots": len(slots)}
     graph_env = os.environ.get("SBM_GRAPH", "0") not in ("", "0")
     if graph_env:
         launch["path"] = "hipGraph replay (SBM_GRAPH)"
-    elif wl.stage == "match" and B > 1 and not banded and not os.environ.get("SBM_BENCH_NO_ADAPT"):
+    elif wl.stage != "match" or B == 1 or banded:
+        # nothing to choose: the library's own default (auto: captured-graph replay of the template loop / the batch once several
+        # calls are in flight and an argument tuple repeats; plain launches for one frame at a time)
+        launch["path"] = "library default (sbm_set_graph_mode auto)"
+    elif not os.environ.get("SBM_BENCH_NO_ADAPT"):
+        for sl in slots:
+            sl.ctx.set_graph_mode(False)  # the library's default with several batches in flight is replay: opt out for the A/B
         t_stream = probe()
         issue_stream = last_issue_s[0] / 40 * 1e6
         for sl in slots:

@@ -157,14 +157,22 @@ int sbm_match_batch_device(sbm_ctx* ctx, const void* d_imgs, int64_t frame_strid
                            int32_t cols, int32_t stride, int32_t channels, const void* d_mask, float threshold,
                            void* d_out, int64_t cap, void* d_counts, void* stream);
 
-/* sbm_match_device records its kernel sequence once per distinct argument tuple
- * as a hipGraph (two branches: the fine levels' linear memories are built
- * while the coarse-level chain runs) and replays it with one hipGraphLaunch per
- * frame.  enabled = 0 uses plain stream launches (also used whenever profiling
- * is on).  Default: disabled — on ROCm 7.2 / MI355X the replayed graph measured
- * slower than the eight stream launches it replaces (74 us linear, 85 us with
- * the fork, against 70 us). */
+/* hipGraph replay of an entry point's launches: the kernel sequence of a call is recorded once per distinct argument
+ * tuple (stream capture) and replayed with one hipGraphLaunch.
+ *   enabled = -1 (default, "auto"): sbm_match_batch_device and sbm_match_templates_device replay once the caller keeps
+ *       several calls in flight (sbm_set_pipeline_depth >= 2) and an argument tuple comes back (a tuple is captured at
+ *       its second sighting; up to 16 captures are kept; a caller whose tuples never repeat stays on stream launches).
+ *       Why: with several streams in flight about one process in eight on the MI355X pool runs its stream launches in a
+ *       slow mode (0.5 - 1.8 ms per 16-frame step instead of 0.11, kernel durations unchanged) that replay -- one host
+ *       call per step -- does not have; otherwise the two measure the same.  sbm_match_device (one frame at a time)
+ *       stays on stream launches: there the replayed graph is slower (74 - 85 us against 70 us on ROCm 7.2).
+ *   enabled = 0: never (the opt-out; also what profiling uses).
+ *   enabled = 1: always, sbm_match_device included (two branches: the fine levels' linear memories are built while the
+ *       coarse-level chain runs).
+ * Results are identical either way. */
 int sbm_set_graph_mode(sbm_ctx* ctx, int32_t enabled);
+/* How many captured graphs the context holds right now (a test / diagnostics accessor for the rule above). */
+int sbm_graph_count(sbm_ctx* ctx, int32_t* n_graphs);
 
 /* Which gradient kernel (quantizedOrientations + hysteresisGradient, line2Dup.cpp:313-404, :218-311) the match
  * entry points launch.  mode 0 (default): by launch size — the row-streaming kernel (one wave per 256-column

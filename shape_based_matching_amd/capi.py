@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "sbm_select_templates", "sbm_partition_templates", "sbm_match_sharded",
     "sbm_match_batch_host", "sbm_match_batch_host_begin", "sbm_match_batch_host_end", "sbm_extract_local_maxima",
     "sbm_set_pipeline_depth", "sbm_set_coarse_mode", "sbm_set_refine_order", "sbm_get_coarse_bitplanes",
-    "sbm_comm_count", "sbm_match_templates_device_sharded",
+    "sbm_comm_count", "sbm_match_templates_device_sharded", "sbm_graph_count",
 ]
 
 
@@ -135,6 +135,7 @@ def lib() -> C.CDLL:
     L.sbm_get_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.sbm_set_result_mirror.argtypes = [vp, vp, vp]
     L.sbm_set_graph_mode.argtypes = [vp, i32]
+    L.sbm_graph_count.argtypes = [vp, C.POINTER(i32)]
     L.sbm_set_quantize_mode.argtypes = [vp, i32, i32]
     L.sbm_resize_linear.argtypes = [vp, vp, i32, i32, i32, i32, C.c_double, C.c_double, vp, i64, C.POINTER(i32), C.POINTER(i32)]
     L.sbm_match_templates_device.argtypes = [vp, f32, vp, i64, vp, vp]
@@ -400,8 +401,15 @@ class Context:
         """hint: the caller keeps this many batches in flight on the GPU -> launches are sized for throughput (>= 2)"""
         _check(lib().sbm_set_pipeline_depth(self._h, batches_in_flight))
 
-    def set_graph_mode(self, on: bool):
-        _check(lib().sbm_set_graph_mode(self._h, 1 if on else 0))
+    def graph_count(self) -> int:
+        n = C.c_int32(0)
+        _check(lib().sbm_graph_count(self._h, C.byref(n)))
+        return int(n.value)
+
+    def set_graph_mode(self, on):
+        """True: always replay captured hipGraphs; False: never; None / "auto" (the library's default): batch and template-loop
+        entry points replay once several calls are in flight (set_pipeline_depth >= 2) and an argument tuple repeats"""
+        _check(lib().sbm_set_graph_mode(self._h, -1 if on is None or on == "auto" else (1 if on else 0)))
 
     # -- pyramid state ------------------------------------------------------------
     def build_pyramid(self, img: np.ndarray, mask: Optional[np.ndarray] = None):

@@ -482,6 +482,82 @@ def test_match_batch_device_graph_replay(oracle, ctx_factory, case1):
             run_and_check(order, mirror)
 
 
+def test_graph_replay_is_the_default_with_several_calls_in_flight(oracle, ctx_factory, case1):
+    """Round 4 (sbm_set_graph_mode auto): a caller that tells the context it keeps several calls in flight
+    (sbm_set_pipeline_depth >= 2) gets captured-graph replay of the batch entry point and of the template-loop entry point
+    without asking for it -- from the SECOND sighting of an argument tuple; with one call in flight, with tuples that never
+    repeat, or after the opt-out nothing is captured.  Four contexts side by side (the bench's four slots): same lists."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    ts = case1["templates"].subset(range(280, 361, 2))
+    base = frame_of(case1)
+    frames = np.stack([base, np.ascontiguousarray(base[:, ::-1]), np.roll(base, 48, axis=1)])
+    rows, cols = base.shape[:2]
+    B, cap, rec, thr = len(frames), 1024, MATCH_DTYPE.itemsize, 85.0
+    want = []
+    for fr in frames:
+        pyr = oracle.Pyramid.build(fr, [4, 8], 30.0)
+        want.append(key(pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr)))
+        pyr.free()
+    assert len(want[0]) > 0
+    d_imgs = [torch.from_numpy(frames).to(dev) for _ in range(3)]
+    fs = rows * cols * 3
+
+    class Slot:
+        def __init__(self):
+            self.ctx = ctx_factory()
+            self.ctx.upload_templates(ts)
+            self.stream = torch.cuda.Stream(device=dev)
+            self.d_out = torch.zeros(B * cap * rec, dtype=torch.uint8, device=dev)
+            self.d_cnt = torch.zeros(B * 2, dtype=torch.int32, device=dev)
+
+        def run(self, img):
+            self.ctx.match_batch_device(img.data_ptr(), fs, B, rows, cols, cols * 3, 3, thr, self.d_out.data_ptr(), cap, self.d_cnt.data_ptr(),
+                                        stream=self.stream.cuda_stream)
+
+        def check(self):
+            self.stream.synchronize()
+            cnt = self.d_cnt.cpu().numpy().reshape(-1, 2)
+            out = self.d_out.cpu().numpy().reshape(B, cap * rec)
+            for f in range(B):
+                assert cnt[f, 1] == 0 and key(out[f].view(MATCH_DTYPE)[: cnt[f, 0]]) == want[f], f
+
+    slots = [Slot() for _ in range(4)]
+    torch.cuda.synchronize()
+    s0 = slots[0]
+    for _ in range(3):  # one call in flight (the default hint): plain launches
+        s0.run(d_imgs[0])
+        s0.check()
+    assert s0.ctx.graph_count() == 0
+    for sl in slots:
+        sl.ctx.set_pipeline_depth(4)
+    for rep in range(4):  # four contexts round-robin over two input buffers, nothing synchronised in between
+        for i, sl in enumerate(slots):
+            sl.run(d_imgs[(rep + i) % 2])
+        if rep == 0:
+            assert all(sl.ctx.graph_count() == 0 for sl in slots)  # first sighting of every tuple: stream launches
+    for sl in slots:
+        sl.check()
+        assert sl.ctx.graph_count() == 2  # one capture per (context, input buffer)
+    s0.ctx.set_graph_mode(False)  # the opt-out drops the captures
+    s0.run(d_imgs[0])
+    s0.check()
+    assert s0.ctx.graph_count() == 0
+    s0.ctx.set_graph_mode("auto")
+    # the template loop alone (BASELINE configs 3 and 4 step this way) on what the last call left resident
+    d_out = torch.zeros(cap * rec, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    for rep in range(3):
+        d_cnt.fill_(-1)
+        torch.cuda.synchronize()
+        s0.ctx.match_templates_device(thr, d_out.data_ptr(), cap, d_cnt.data_ptr(), stream=s0.stream.cuda_stream)
+        s0.stream.synchronize()
+        n = int(d_cnt.cpu().numpy()[0])
+        assert key(d_out.cpu().numpy().view(MATCH_DTYPE)[:n]) == want[0], rep
+        assert s0.ctx.graph_count() == (0 if rep == 0 else 1)
+
+
 @pytest.mark.parametrize("with_comm", [False, True])
 def test_match_batch_device_banded_equals_whole_level_build(oracle, ctx_factory, case1, with_comm):
     """Round 3, build-sharded step on one GPU: the gradient stage launched band by band (2, 4 and 8 row bands, each widened
