@@ -279,6 +279,74 @@ __device__ __forceinline__ void build_lm_rows_item(const uint8_t* __restrict__ q
     }
 }
 
+// Strip-interleaved spread plane of a T = 4 level, ALL FOUR ty of a grid row per thread (round 4).  build_lm_rows_item
+// gives every (ty, gy) pixel row a thread of its own, which loads the T source rows ty .. ty+T-1 of its window: every
+// source row is loaded T times and OR-ed T times.  Here a thread owns 4 grid cells of one GRID row gy for all ty: it loads
+// the 2T-1 = 7 source rows gy*4 .. gy*4+6 once, forms the four vertical windows from suffix ORs of the first four rows and
+// prefix ORs of the next three (V_ty = rows[ty..3] | rows[4..3+ty]), and then does per ty what the other form does: OR of
+// T pixels forward, register transpose, LDS hop so that a wave stores one strip (runs of 256 bytes).  A workgroup = 16
+// grid rows x 64 cells x 4 ty; 16 KB of LDS.  7 row loads and ~45 ORs per 16 stored dwords instead of 16 and ~80.
+__device__ __forceinline__ void build_lm_strip4_allty(const uint8_t* __restrict__ q, int rows, int cols, int W, int H,
+                                                      uint8_t* __restrict__ lm, int64_t blk, uint32_t* s_tile4)
+{
+    constexpr int T = 4;
+    const int n_cb = (W + 63) >> 6;
+    const int t = (int)threadIdx.x;
+    const int tile_cb = (int)(blk % n_cb), tile_gyb = (int)(blk / n_cb);
+    const int row = t >> 4, kk = t & 15;
+    const int gy = tile_gyb * 16 + row, k = tile_cb * 16 + kk;
+    const bool active = gy < H && k * 4 < W;
+    const int c0 = (active ? k : 0) * 16; // first pixel column of this thread's 4 cells
+    uint32_t r[7][5];
+#pragma unroll
+    for (int d = 0; d < 7; ++d) {
+        const int y = gy * T + d;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) r[d][i] = 0;
+        if (active && y < rows) { // rows past the image: zero (the clipped window of spread(), :626-627)
+            const uint8_t* src = q + (size_t)y * cols + c0;
+            const uint4 w = *(const uint4*)src;
+            r[d][0] = w.x, r[d][1] = w.y, r[d][2] = w.z, r[d][3] = w.w;
+            if (c0 + 16 < cols) r[d][4] = *(const uint32_t*)(src + 16); // right halo (zero past the last column)
+        }
+    }
+    // suffix ORs of rows 0..3 (in place: r[d] = rows d..3), prefix ORs of rows 4..6 (r[4+d] = rows 4..4+d)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        r[2][i] |= r[3][i];
+        r[1][i] |= r[2][i];
+        r[0][i] |= r[1][i];
+        r[5][i] |= r[4][i];
+        r[6][i] |= r[5][i];
+    }
+#pragma unroll
+    for (int ty = 0; ty < T; ++ty) {
+        uint32_t v[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v[i] = ty == 0 ? r[0][i] : (r[ty][i] | r[3 + ty][i]);
+        // horizontal OR over 4 pixels forward: byte c |= bytes c+1 .. c+3; dword i = cell i, byte tx = sub-column tx
+        uint32_t sp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            sp[i] = v[i] | __builtin_amdgcn_alignbyte(v[i + 1], v[i], 1) | __builtin_amdgcn_alignbyte(v[i + 1], v[i], 2) |
+                    __builtin_amdgcn_alignbyte(v[i + 1], v[i], 3);
+        // per tx the 4 cells' bytes in one dword (4 x 4 byte transpose)
+#pragma unroll
+        for (int tx = 0; tx < T; ++tx) {
+            const uint32_t p01 = perm_b32(sp[1], sp[0], 0x0c0c0000u | ((4 + tx) << 8) | tx);
+            const uint32_t p23 = perm_b32(sp[3], sp[2], 0x00000c0cu | ((4 + tx) << 24) | (tx << 16));
+            s_tile4[(ty * T + tx) * 256 + (kk >> 2) * 64 + row * 4 + (kk & 3)] = p01 | p23;
+        }
+    }
+    __syncthreads();
+    const int S = tile_cb * 4 + (t >> 6), gy2 = tile_gyb * 16 + ((t & 63) >> 2);
+    if (S < (W >> 4) && gy2 < H) {
+#pragma unroll
+        for (int sub = 0; sub < T * T; ++sub)
+            *(uint32_t*)(lm + lm_strip_offset(sub, gy2, S * 16 + (t & 3) * 4, W, H)) = s_tile4[sub * 256 + t];
+    }
+}
+
 // All pyramid levels in one launch: block ranges per level (levels whose T is 4 or 8), plus the
 // reset of the per-frame counters, so the whole linear-memory stage costs one kernel boundary.
 struct LmLevelArgs {
@@ -292,6 +360,7 @@ struct LmLevelArgs {
                          // reads): 1/8 of the stores and of the HBM write-back; 2: the same plane strip-interleaved;
                          // 3: lm is the coarsest level's 16 BIT planes (lm_stride bits each; sbm_coarse_bits.h)
     int32_t split;       // 8-plane levels: LM_FULL_SPLIT work items per (pixel row, 4 cells) instead of 1
+    int32_t allty;       // compact == 2, T == 4: one thread per (grid row, 4 cells) for all four ty (build_lm_strip4_allty)
 };
 struct LmArgs {
     LmLevelArgs lv[SBM_MAX_LEVELS];
@@ -303,7 +372,7 @@ struct LmArgs {
 __global__ __launch_bounds__(256) void k_build_lm_rows(const LmArgs a)
 {
     raise_wave_priority();
-    __shared__ uint32_t s_tile[8 * 256]; // strip levels: the workgroup's spread dwords, [tx][strip][row][4 cells]
+    __shared__ uint32_t s_tile[16 * 256]; // strip levels: the workgroup's spread dwords, [tx][strip][row][4 cells] ([ty][tx].. all-ty form)
     const size_t frame = blockIdx.y; // batch of frames: one grid row each
     if (blockIdx.x == 0 && a.counters) {
         if (threadIdx.x < CTR_STRIDE) a.counters[frame * CTR_STRIDE + threadIdx.x] = 0;
@@ -318,7 +387,8 @@ __global__ __launch_bounds__(256) void k_build_lm_rows(const LmArgs a)
     const int64_t item = (int64_t)((int)blockIdx.x - p.block_begin) * 256 + threadIdx.x;
     const uint8_t* q = p.q + frame * p.q_fs;
     uint8_t* lm = p.lm + frame * p.lm_fs;
-    if (p.T == 4) build_lm_rows_item<4>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact, p.split, s_tile);
+    if (p.allty) build_lm_strip4_allty(q, p.rows, p.cols, p.W, p.H, lm, (int64_t)((int)blockIdx.x - p.block_begin), s_tile);
+    else if (p.T == 4) build_lm_rows_item<4>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact, p.split, s_tile);
     else build_lm_rows_item<8>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact, p.split, s_tile);
 }
 
