@@ -65,14 +65,16 @@ __global__ __launch_bounds__(256) void k_pack_bitplanes(const uint8_t* __restric
 }
 
 // One pass over the template's nf features on one bit-plane set.  ub: the plane set of this frame (wave-uniform);
-// li: this lane's dword of bit 0 of the item (item base / 32 + lane), or 0 for a lane whose loads do not matter (it
+// li: this lane's first dword of the item (item base / 32 + DW * lane), or 0 for a lane whose loads do not matter (it
 // then reads the features' own first dwords: one more cache line per load, no branch).  MISSES: count zero bits and
-// stop when every position is dead, else count one bits.
+// stop when every position is dead, else count one bits.  DW: dwords (32 positions each) a lane owns.
 // soff: the template's feature offsets (bits == bytes, see above); sel: the first 64 of them, one per lane.
 // Returns false when pass A ended with no position alive.
-template <int P, bool MISSES, bool WIDE>
+typedef uint32_t cb_u32x2 __attribute__((ext_vector_type(2)));
+
+template <int P, bool MISSES, bool WIDE, int DW>
 __device__ __forceinline__ bool bit_pass(const uint32_t* __restrict__ ub, uint32_t li, const int32_t* __restrict__ soff, int sel, int nf,
-                                         int zero_off, uint32_t (&c)[P], uint32_t& dead)
+                                         int zero_off, uint32_t (&c)[DW][P], uint32_t (&dead)[DW])
 {
     const int lane = threadIdx.x & 63;
     const uint32_t li4 = li << 2;
@@ -83,28 +85,40 @@ __device__ __forceinline__ bool bit_pass(const uint32_t* __restrict__ ub, uint32
     auto batch = [&](int g, auto n_, auto tail) {
         constexpr int N = decltype(n_)::value;
         constexpr bool TAIL = decltype(tail)::value;
-        uint32_t lo[N];
+        uint32_t lo[N][DW];
         int sh[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const uint32_t o = (uint32_t)__builtin_amdgcn_readlane(sel, (g + k) & 63);
             sh[k] = (int)(o & 31u);
             // buffer load: plane set (resource) + this lane's byte offset (VGPR) + the feature's dword (SGPR): no address arithmetic
-            lo[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)li4, (int)((o >> 5) << 2), 0);
+            if (DW == 1) {
+                lo[k][0] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)li4, (int)((o >> 5) << 2), 0);
+            } else {
+                const cb_u32x2 v2 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)li4, (int)((o >> 5) << 2), 0);
+                lo[k][0] = v2.x;
+                lo[k][DW - 1] = v2.y;
+            }
         }
 #pragma unroll
         for (int h = 0; h < N; h += 8) {
-            uint32_t x[8];
+            uint32_t x[DW][8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                // lane i's upper dword = lane i+1's load (wave_shl:1; lane 63 reads 0 -- it owns no position)
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo[h + k], 0x130, 0xf, 0xf, true);
-                const uint32_t v = __builtin_amdgcn_alignbit(hi, lo[h + k], (uint32_t)sh[h + k]);
-                x[k] = MISSES ? ~v : v;
-                if (TAIL && g + h + k >= nf) x[k] = 0u; // wave-uniform
+                // the dword after the lane's own = lane i+1's first (wave_shl:1; lane 63 reads 0 -- it owns no position)
+                const uint32_t nx = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo[h + k][0], 0x130, 0xf, 0xf, true);
+#pragma unroll
+                for (int w = 0; w < DW; ++w) {
+                    const uint32_t v = __builtin_amdgcn_alignbit(w + 1 < DW ? lo[h + k][w + 1] : nx, lo[h + k][w], (uint32_t)sh[h + k]);
+                    x[w][k] = MISSES ? ~v : v;
+                    if (TAIL && g + h + k >= nf) x[w][k] = 0u; // wave-uniform
+                }
             }
-            const uint32_t carry = bitslice_add8<P>(c, x);
-            if (MISSES) dead |= carry;
+#pragma unroll
+            for (int w = 0; w < DW; ++w) {
+                const uint32_t carry = bitslice_add8<P>(c[w], x[w]);
+                if (MISSES) dead[w] |= carry;
+            }
         }
     };
     // the NEXT 64 offsets are fetched while the current 64 are being worked on
@@ -127,14 +141,22 @@ __device__ __forceinline__ bool bit_pass(const uint32_t* __restrict__ ub, uint32
             else batch(g, std::integral_constant<int, 16>{}, std::true_type{});
             g += 16;
         }
-        if (MISSES && __builtin_amdgcn_ballot_w64(~dead != 0u) == 0ull) return false;
+        if (MISSES) {
+            uint32_t alive = ~dead[0];
+#pragma unroll
+            for (int w = 1; w < DW; ++w) alive |= ~dead[w];
+            if (__builtin_amdgcn_ballot_w64(alive != 0u) == 0ull) return false;
+        }
     }
     return true;
 }
 
-// grid = (items of CB_POS positions, active templates / 4, frames); block = 4 waves = 4 template slots.
+// grid = (items of 2016 * DW positions, active templates / 4, frames); block = 4 waves = 4 template slots.
 // blm: [frames][16 planes][lm_stride / 32 dwords]; P: counter planes, 2^P > the largest nf of the launch.
-template <int P, bool WIDE>
+// DW = 2: a lane owns 64 positions (an 8-byte load per feature): half as many, twice as long work items -- for launches
+// whose one-dword items would not all be resident at once (8 waves per SIMD): the second round of waves starts when the
+// first ends, and a launch takes two "longest waves" instead of one (16 case1 frames: 25.2 -> see DESIGN.md).
+template <int P, bool WIDE, int DW>
 __global__ __launch_bounds__(256) void k_similarity_coarse_bits(
     const uint32_t* __restrict__ blm, int64_t lm_stride, int T, int W, int H, int L, int lc, const DevTL* __restrict__ tls,
     const int32_t* __restrict__ soff, const CoarseItem* __restrict__ items, const int32_t* __restrict__ cfoff, int n_active,
@@ -151,56 +173,67 @@ __global__ __launch_bounds__(256) void k_similarity_coarse_bits(
     const CoarseItem it = items[templ_slot];
     const int nf = __builtin_amdgcn_readfirstlane(it.nf), rmin = __builtin_amdgcn_readfirstlane(it.rmin);
     const int npos = __builtin_amdgcn_readfirstlane(it.npos);
-    const int base = chunk_id * CB_POS;
+    constexpr int LP = 32 * DW; // positions per lane
+    const int base = chunk_id * (CB_POS * DW);
     if (base >= npos || nf <= 0) return; // rmin >= 1 (host): positions past the span score 0 and are never candidates
     const int M = (4 * nf - rmin) >> 2;  // misses a position can afford
     if (4 * nf < rmin) return;
     const int zero_off = (int)(7 * lm_stride + (int64_t)T * T * W * H);
-    // this lane's positions base + 32 lane + b, b < nvalid
-    int nvalid = npos - base - 32 * lane;
-    nvalid = lane == 63 ? 0 : (nvalid < 0 ? 0 : (nvalid > 32 ? 32 : nvalid));
-    const uint32_t valid = nvalid == 32 ? ~0u : ((1u << nvalid) - 1u);
-    const bool on = base + 32 * lane < npos + 32; // own positions or the left neighbour's upper dword
+    const bool on = base + LP * lane < npos + LP; // own positions or the left neighbour's last dword
     const uint32_t* ub = blm + (size_t)frame * blm_fs_dwords;
-    const uint32_t li = (uint32_t)((base >> 5) + lane);
+    const uint32_t li = (uint32_t)((base >> 5) + DW * lane);
     const int32_t* so = soff + it.soff_base;
 
-    uint32_t ca[P];
+    uint32_t ca[DW][P], dead[DW];
     const int bias = (1 << P) - 1 - M;
 #pragma unroll
-    for (int p = 0; p < P; ++p) ca[p] = (bias >> p) & 1 ? ~0u : 0u;
-    uint32_t dead = ~valid;
-    if (!bit_pass<P, true, WIDE>(ub, on ? li : 0u, so, sel0, nf, zero_off, ca, dead)) return;
-
-    // survivors: exact hits of the lanes that hold one (and of their right neighbours, for the upper dword)
-    const uint32_t alive = ~dead;
-    const uint32_t left_alive = (uint32_t)__builtin_amdgcn_mov_dpp((int)alive, 0x138, 0xf, 0xf, true); // wave_shr:1
-    uint32_t ce[P];
+    for (int w = 0; w < DW; ++w) {
+        // this lane's positions base + LP lane + 32 w + b, b < nvalid (lane 63 only supplies lane 62's last dword)
+        int nvalid = npos - base - LP * lane - 32 * w;
+        nvalid = lane == 63 ? 0 : (nvalid < 0 ? 0 : (nvalid > 32 ? 32 : nvalid));
+        dead[w] = ~(nvalid == 32 ? ~0u : ((1u << nvalid) - 1u));
 #pragma unroll
-    for (int p = 0; p < P; ++p) ce[p] = 0;
-    uint32_t unused = 0;
-    bit_pass<P, false, WIDE>(ub + ((8 * lm_stride) >> 5), (alive | left_alive) != 0u ? li : 0u, so, sel0, nf, zero_off, ce, unused);
+        for (int p = 0; p < P; ++p) ca[w][p] = (bias >> p) & 1 ? ~0u : 0u;
+    }
+    if (!bit_pass<P, true, WIDE, DW>(ub, on ? li : 0u, so, sel0, nf, zero_off, ca, dead)) return;
+
+    // survivors: exact hits of the lanes that hold one (and of their right neighbours, for the dword after their own)
+    uint32_t alive_any = ~dead[0];
+#pragma unroll
+    for (int w = 1; w < DW; ++w) alive_any |= ~dead[w];
+    const uint32_t left_alive = (uint32_t)__builtin_amdgcn_mov_dpp((int)alive_any, 0x138, 0xf, 0xf, true); // wave_shr:1
+    uint32_t ce[DW][P], unused[DW];
+#pragma unroll
+    for (int w = 0; w < DW; ++w) {
+        unused[w] = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) ce[w][p] = 0;
+    }
+    bit_pass<P, false, WIDE, DW>(ub + ((8 * lm_stride) >> 5), (alive_any | left_alive) != 0u ? li : 0u, so, sel0, nf, zero_off, ce, unused);
 
     cands += (size_t)frame * cap;
     counters += (size_t)frame * CTR_STRIDE;
     const int offset = T / 2 + (T % 2 - 1);
-    uint32_t m = alive;
-    while (m) {
-        const int b = __builtin_ctz(m);
-        m &= m - 1;
-        const int misses = bitslice_get<P>(ca, b) - bias;
-        const int raw = 3 * (nf - misses) + bitslice_get<P>(ce, b);
-        if (raw >= rmin) {
-            const int j = base + 32 * lane + b;
-            const int idx = atomicAdd(&counters[0], 1);
-            if (idx < cap) {
-                Cand c;
-                c.t = it.t;
-                c.x = (j % W) * T + offset;
-                c.y = (j / W) * T + offset;
-                c.raw = raw;
-                cand_fill_next(c, tls, raw_keep, class_idx, template_id, L, lc - 1);
-                cands[idx] = c;
+#pragma unroll
+    for (int w = 0; w < DW; ++w) {
+        uint32_t m = ~dead[w];
+        while (m) {
+            const int b = __builtin_ctz(m);
+            m &= m - 1;
+            const int misses = bitslice_get<P>(ca[w], b) - bias;
+            const int raw = 3 * (nf - misses) + bitslice_get<P>(ce[w], b);
+            if (raw >= rmin) {
+                const int j = base + LP * lane + 32 * w + b;
+                const int idx = atomicAdd(&counters[0], 1);
+                if (idx < cap) {
+                    Cand c;
+                    c.t = it.t;
+                    c.x = (j % W) * T + offset;
+                    c.y = (j / W) * T + offset;
+                    c.raw = raw;
+                    cand_fill_next(c, tls, raw_keep, class_idx, template_id, L, lc - 1);
+                    cands[idx] = c;
+                }
             }
         }
     }
