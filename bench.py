@@ -38,6 +38,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_ISSUE_CEILING = 0.6e12  # wave-instructions per second the chip issues of the integer mix these kernels are made of
+                             # (v_dot2 / v_pk_* / v_perm / v_alignbit / DPP / v_bitop3: one per 4.1 cycles and SIMD; measured,
+                             # tools/valu_rate.hip, profiles/r02_valu_issue_rates.txt)
 THRESHOLD = 90.0
 T_LEVELS = (4, 8)
 PREFETCH = 256  # capacity (records) of the per-frame match list exchanged between ranks / sent to the host
@@ -204,7 +207,8 @@ def cpu_baseline(ts, frame, budget_s: float = 12.0):
         "unit": "templates*Mpixels/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{reps} full match() calls of the bench frame with {ts.n_templates} templates "
+        "sample": f"oracle/sbm_oracle.c (plain C, gcc -O3 -mavx2 -fopenmp -ffp-contract=off: compiler-vectorised, no hand-written SIMD); "
+                  f"{reps} full match() calls of the bench frame with {ts.n_templates} templates "
                   f"({per * 1e3:.1f} ms each, {len(last[0])} raw matches) on {threads} thread(s): row-band parallel pyramid "
                   f"build + OpenMP template loop; host has {ncpu} logical cores, {usable} usable by this process",
         "ms_per_match": per * 1e3,
@@ -537,6 +541,17 @@ def main():
         # nothing to choose: the library's own default (auto: captured-graph replay of the template loop / the batch once several
         # calls are in flight and an argument tuple repeats; plain launches for one frame at a time)
         launch["path"] = "library default (sbm_set_graph_mode auto)"
+        if len(slots) > 1 and not os.environ.get("SBM_BENCH_NO_ADAPT"):
+            # ... but how many calls to keep in flight is the caller's choice: some processes on this pool run launches that
+            # alternate over several streams slowly, and a 20 us template loop then steps faster from
+            # one slot (c3: 42 us per step with two slots against 27 with one in such a process, 20.5 against 26 otherwise)
+            t_all = probe()
+            active[0] = slots[:1]
+            t_one = probe()
+            launch["probe_us_per_step"] = {f"{len(slots)} slots": round(t_all, 1), "one slot": round(t_one, 1)}
+            if t_one < 0.95 * t_all:
+                launch["slots"] = 1
+            active[0] = slots[: launch["slots"]]
     elif not os.environ.get("SBM_BENCH_NO_ADAPT"):
         for sl in slots:
             sl.ctx.set_graph_mode(False)  # the library's default with several batches in flight is replay: opt out for the A/B
@@ -763,9 +778,10 @@ def main():
         limiter = {
             "k_quantize": "vector-instruction issue (integer VALU at one wave-instruction per 4 cycles per SIMD); HBM traffic "
                           "equals the algorithmic bytes",
-            "k_build_lm": "HBM writes of the linear memories",
-            "k_similarity_coarse": "per-item latency chain + L2 -> L1 bandwidth of the items still alive (exact pruning: most of the "
-                                   "algorithmic bytes are never loaded)",
+            "k_build_lm": "memory latency of a short load - compute - store item (HBM traffic 45 MB per 16-frame launch)",
+            "k_similarity_coarse": "bit-plane kernel: vector issue of the bit-sliced counters and L2 -> L1 bandwidth of the items still "
+                                   "alive on large template sets (c4: both near their ceilings); the longest work items' chain of "
+                                   "dependent L2 round trips on a 16-frame case1 launch",
             "k_similarity_local": "L2 line traffic of the 16x16 patch reads + vector issue of the response LUT",
         }
         for name in kern:
@@ -776,20 +792,34 @@ def main():
         dom_bytes = float(sum(alg[dom])) / kern[dom]["launches"]
         dom_s = kern[dom]["avg_launch_us"] * 1e-6
         achieved = dom_bytes / dom_s / 1e9
-        # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE, WRITE_SIZE in
-        # separate runs, gfx950 correction applied: profiles/pmc_traffic.json, tools/make_pmc_json.py).  For the kernels
-        # that no longer touch all their algorithmic bytes (k_build_lm writes one spread plane instead of eight at the
-        # refinement levels; the coarse pass prunes) the fraction of the HBM roofline is the counter-based one.
+        # Counter-based figures per kernel, from the committed rocprofv3 --pmc passes of this same configuration
+        # (profiles/r04_pmc.json: FETCH_SIZE / WRITE_SIZE / SQ / TCC passes, each in a run of its own, gfx950 FETCH correction
+        # applied where the guide prescribes it -- tools/r04_profile.sh, tools/r04_pmc_json.py) combined with THIS run's launch
+        # durations:  hbm_frac = HBM-side bytes / duration / 8 TB/s;  valu_issue_frac = vector instructions per wave x waves /
+        # duration / the measured issue ceiling of this instruction mix (0.6 T wave-instructions per second: 1024 SIMDs x 2.4
+        # GHz / 4.1 cycles, profiles/r02_valu_issue_rates.txt);  l2_GBps = L2 requests (128-byte lines) x 128 / duration.
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and args.config == "case1" and B == 16:
+        pmc = os.path.join(ROOT, "profiles", "r04_pmc.json")
+        pmc_key = args.config if ((args.config == "case1" and B == 16 and args.frame == "scene" and count == 360) or
+                                  (args.config == "c3" and count == 3600) or (args.config == "c4" and count == 4500) or
+                                  (args.config == "c5" and B == 64)) else None
+        if os.path.exists(pmc) and pmc_key and world == 1:
             try:
-                pj = json.load(open(pmc))
+                pj = json.load(open(pmc)).get(pmc_key, {})
                 for name in kern:
-                    if name in pj:
-                        kern[name]["hbm_traffic_bytes_per_launch"] = float(pj[name])
-                        kern[name]["hbm_frac"] = float(pj[name]) / (kern[name]["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-                traffic = pj.get(dom)
+                    e = pj.get(name)
+                    if not e:
+                        continue
+                    t_s = kern[name]["avg_launch_us"] * 1e-6
+                    kern[name]["hbm_traffic_bytes_per_launch"] = float(e["hbm_bytes_per_launch"])
+                    kern[name]["hbm_frac"] = float(e["hbm_bytes_per_launch"]) / t_s / 1e9 / HBM_PEAK_GBS
+                    kern[name]["valu_issue_frac"] = float(e["valu_per_wave"]) * float(e["waves"]) / t_s / VALU_ISSUE_CEILING
+                    if e.get("l2_requests"):
+                        kern[name]["l2_GBps"] = float(e["l2_requests"]) * 128.0 / t_s / 1e9
+                        kern[name]["l2_hit_rate"] = e.get("l2_hit_rate")
+                    kern[name]["wait_inst_any_pct"] = e.get("wait_inst_any_pct")
+                    kern[name]["active_valu_pct"] = e.get("active_valu_pct")
+                traffic = kern.get(dom, {}).get("hbm_traffic_bytes_per_launch")
             except Exception:
                 traffic = None
         total_templates = wl.n_total if wl.maps is not None else ts.n_templates
@@ -861,11 +891,18 @@ def main():
                 "bound": "hbm",
                 "limiter": limiter.get(dom, ""),
                 "kernel": dom,
-                "achieved": achieved,
+                # `achieved` is algorithmic bytes / time, as the contract defines it -- EXCEPT when the dominant kernel is the
+                # coarse pass: its algorithmic bytes are the reference's one byte per (template, feature, position), of which the
+                # bit-plane kernel loads one or two BITS and, after the exact pruning, most not at all; that quotient is a work
+                # rate (`work_rate_GBps`), not a bandwidth, so `achieved` / `frac` are then the counter-based HBM figure
+                "achieved": (achieved if dom != "k_similarity_coarse" or traffic is None else traffic / dom_s / 1e9),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "frac": (achieved if dom != "k_similarity_coarse" or traffic is None else traffic / dom_s / 1e9) / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "work_rate_GBps": achieved,
+                "valu_issue_frac": kern[dom].get("valu_issue_frac"),
+                "l2_GBps": kern[dom].get("l2_GBps"),
                 "algorithmic_bytes_per_launch": dom_bytes,
                 "avg_launch_us": kern[dom]["avg_launch_us"],
                 "frac_on_other_frames": frac_by_frame if extra else None,
@@ -877,7 +914,11 @@ def main():
                                                                if "hbm_traffic_bytes_per_launch" in v)),
                                 "ms_per_step": elapsed / args.steps * 1e3,
                                 "hbm_frac": float(sum(v["hbm_traffic_bytes_per_launch"] * v["launches"] for v in kern.values()
-                                                      if "hbm_traffic_bytes_per_launch" in v)) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}
+                                                      if "hbm_traffic_bytes_per_launch" in v)) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                # vector instructions of all the step's launches (counted one batch at a time) over the
+                                # pipelined step's time: what the overlapping batches actually saturate
+                                "valu_issue_frac": float(sum(v["valu_issue_frac"] * v["avg_launch_us"] * v["launches"] for v in kern.values()
+                                                             if v.get("valu_issue_frac") is not None)) * 1e-6 / (elapsed / args.steps)}
                                if traffic is not None else None),
             },
             "kernels": kern,
