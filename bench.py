@@ -801,15 +801,23 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r04_pmc.json")
         pmc_key = args.config if ((args.config == "case1" and B == 16 and args.frame == "scene" and count == 360) or
-                                  (args.config == "c3" and count == 3600) or (args.config == "c4" and count == 4500) or
+                                  (args.config == "c3" and count == 3600) or args.config == "c4" or
                                   (args.config == "c5" and B == 64)) else None
         if os.path.exists(pmc) and pmc_key and world == 1:
             try:
                 pj = json.load(open(pmc)).get(pmc_key, {})
+                # c4's counters were collected at one rank's share (4 500 templates); every template of that configuration
+                # does the same work, so the template loop's per-launch figures scale with the template count
+                scale = count / 4500.0 if args.config == "c4" else 1.0
                 for name in kern:
                     e = pj.get(name)
                     if not e:
                         continue
+                    if scale != 1.0:
+                        if not name.startswith("k_similarity"):
+                            continue
+                        e = dict(e, hbm_bytes_per_launch=e["hbm_bytes_per_launch"] * scale, waves=e["waves"] * scale,
+                                 l2_requests=(e.get("l2_requests") or 0.0) * scale)
                     t_s = kern[name]["avg_launch_us"] * 1e-6
                     kern[name]["hbm_traffic_bytes_per_launch"] = float(e["hbm_bytes_per_launch"])
                     kern[name]["hbm_frac"] = float(e["hbm_bytes_per_launch"]) / t_s / 1e9 / HBM_PEAK_GBS

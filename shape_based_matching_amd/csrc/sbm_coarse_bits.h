@@ -239,4 +239,111 @@ __global__ __launch_bounds__(256) void k_similarity_coarse_bits(
     }
 }
 
+
+// bit-sliced sum of two P-plane counters (no overflow by the caller's bound)
+template <int P>
+__device__ __forceinline__ void bitslice_sum(uint32_t (&a)[P], const uint32_t (&b)[P])
+{
+    uint32_t carry = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const uint32_t u = a[p] ^ b[p];
+        const uint32_t s_ = u ^ carry;
+        carry = (u & carry) | (~u & a[p]);
+        a[p] = s_;
+    }
+}
+
+// The LATENCY form of the coarse pass on bit planes (one frame, a few hundred templates): a workgroup of EIGHT waves owns
+// one item of 2016 positions -- waves 0..3 count the any-plane hits of a quarter of the template's features each, waves
+// 4..7 the exact-plane hits of the same quarters -- so an item is two or three rounds of loads deep instead of the
+// eleven of the one-wave form (which stops early on most items but is as slow as its longest item: 11.8 us for a 1024^2
+// frame x 360 templates whatever the content).  No pruning: every feature of every item is loaded (26 MB for that frame).
+// The partial counters meet in LDS; wave 0 adds them (bit-sliced), compares the hit count with nf - M (positions that
+// can reach rmin), and for those takes raw = 3 * any + exact.  Same candidates as every other coarse kernel.
+// grid = (items of 2016 positions, active templates, frames); block = 512.
+template <int P>
+__global__ __launch_bounds__(512) void k_similarity_coarse_bits_block(
+    const uint32_t* __restrict__ blm, int64_t lm_stride, int T, int W, int H, int L, int lc, const DevTL* __restrict__ tls,
+    const int32_t* __restrict__ soff, const CoarseItem* __restrict__ items, int n_active, const int32_t* __restrict__ raw_keep,
+    const int32_t* __restrict__ class_idx, const int32_t* __restrict__ template_id, Cand* __restrict__ cands,
+    int32_t* __restrict__ counters, int cap, int64_t blm_fs_dwords)
+{
+    raise_wave_priority();
+    __shared__ uint32_t s_c[8][P][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int chunk_id = blockIdx.x, templ_slot = blockIdx.y, frame = blockIdx.z;
+    const CoarseItem it = items[templ_slot];
+    const int nf = __builtin_amdgcn_readfirstlane(it.nf), rmin = __builtin_amdgcn_readfirstlane(it.rmin);
+    const int npos = __builtin_amdgcn_readfirstlane(it.npos);
+    const int base = chunk_id * CB_POS;
+    if (base >= npos || nf <= 0 || 4 * nf < rmin) return; // block-uniform
+    const int M = (4 * nf - rmin) >> 2; // misses a position can afford
+    const int zero_off = (int)(7 * lm_stride + (int64_t)T * T * W * H);
+    const bool on = base + 32 * lane < npos + 32; // own positions or the left neighbour's upper dword
+    const int pass = wave >> 2, q = wave & 3;
+    const int nq = (nf + 3) >> 2, f0 = q * nq, cnt = nf - f0 < 0 ? 0 : (nf - f0 < nq ? nf - f0 : nq);
+    const uint32_t* ub = blm + (size_t)frame * blm_fs_dwords + (pass ? ((8 * lm_stride) >> 5) : 0);
+    const int32_t* so = soff + it.soff_base + f0;
+    uint32_t c[1][P], unused[1] = {0u};
+#pragma unroll
+    for (int p = 0; p < P; ++p) c[0][p] = 0;
+    if (cnt > 0) {
+        const int sel0 = lane < cnt ? so[lane] : zero_off;
+        bit_pass<P, false, true, 1>(ub, on ? (uint32_t)((base >> 5) + lane) : 0u, so, sel0, cnt, zero_off, c, unused);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) s_c[wave][p][lane] = c[0][p];
+    __syncthreads();
+    if (wave != 0) return;
+    uint32_t h[P], t[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) h[p] = c[0][p];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) t[p] = s_c[w][p][lane];
+        bitslice_sum<P>(h, t);
+    }
+    // positions that can still reach rmin: any-hits >= nf - M (bit-sliced compare against a wave-uniform constant, LSB up)
+    const int K = nf - M;
+    uint32_t ge = ~0u;
+#pragma unroll
+    for (int p = 0; p < P; ++p) ge = ((K >> p) & 1) ? (h[p] & ge) : (h[p] | ge);
+    int nvalid = npos - base - 32 * lane;
+    nvalid = lane == 63 ? 0 : (nvalid < 0 ? 0 : (nvalid > 32 ? 32 : nvalid));
+    uint32_t m = ge & (nvalid == 32 ? ~0u : ((1u << nvalid) - 1u));
+    if (m == 0u) return;
+#pragma unroll
+    for (int p = 0; p < P; ++p) t[p] = s_c[4][p][lane];
+#pragma unroll
+    for (int w = 5; w < 8; ++w) {
+        uint32_t u[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) u[p] = s_c[w][p][lane];
+        bitslice_sum<P>(t, u);
+    }
+    cands += (size_t)frame * cap;
+    counters += (size_t)frame * CTR_STRIDE;
+    const int offset = T / 2 + (T % 2 - 1);
+    while (m) {
+        const int b = __builtin_ctz(m);
+        m &= m - 1;
+        const int raw = 3 * bitslice_get<P>(h, b) + bitslice_get<P>(t, b);
+        if (raw >= rmin) {
+            const int j = base + 32 * lane + b;
+            const int idx = atomicAdd(&counters[0], 1);
+            if (idx < cap) {
+                Cand cd;
+                cd.t = it.t;
+                cd.x = (j % W) * T + offset;
+                cd.y = (j / W) * T + offset;
+                cd.raw = raw;
+                cand_fill_next(cd, tls, raw_keep, class_idx, template_id, L, lc - 1);
+                cands[idx] = cd;
+            }
+        }
+    }
+}
+
 } // namespace sbm
