@@ -175,7 +175,7 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
                                                   float thr_sq, uint8_t* __restrict__ out,
                                                   float* __restrict__ mag_out, float* __restrict__ ori_out,
                                                   uint8_t* __restrict__ pyr_out, int64_t img_fs, int64_t out_fs,
-                                                  int64_t pyr_fs)
+                                                  int64_t pyr_fs, int tile_row0)
 {
     // a batch of frames of one geometry: frame = blockIdx.z, *_fs = bytes from one frame to the next
     img += (size_t)blockIdx.z * img_fs;
@@ -189,7 +189,9 @@ __global__ __launch_bounds__(QN) void k_quantize(const uint8_t* __restrict__ img
     __shared__ uint32_t s_pyr[QT_R / 2][QT_C / 2 * CH / 4]; // pyrDown of the tile, interleaved channels, as dwords
     __shared__ __attribute__((aligned(16))) uint32_t s_nonflat[16]; // per wave: it loaded a word that differs from the tile's first pixel
     const int tid = threadIdx.x;
-    const int R0 = blockIdx.y * QT_R, C0 = blockIdx.x * QT_C;
+    // tile_row0: first tile row of this launch (a launch may cover a band of tile rows: the host entry point starts the
+    // gradient stage on the rows that have arrived while the rest of the frame is still crossing PCIe)
+    const int R0 = ((int)blockIdx.y + tile_row0) * QT_R, C0 = blockIdx.x * QT_C;
     const bool interior = R0 >= 5 && R0 + QT_R + 5 <= rows && C0 >= 8 && C0 + QT_C + 8 <= cols;
     QSTAMP(0)
     // every kernel argument is fetched here, with the first ones: a scalar load issued in the middle of the

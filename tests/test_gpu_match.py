@@ -266,3 +266,17 @@ def test_full_size_gradient_stage_crop_consistency(oracle, ctx_factory):
         nonzero += int(np.count_nonzero(o0[a0:b0, a1:b1]))
         pyr.free()
     assert nonzero > 1000
+
+
+def test_sbm_match_with_the_upload_in_row_bands():
+    """SBM_MATCH_BANDS (off by default: slower on ROCm 7.2, see sbm_capi_match.inc): the frame crosses PCIe in 4 row bands and
+    level 0's gradient tiles are launched band by band behind them; the smoke check (match list and both levels' linear
+    memories against the oracle) must hold in a process that has the knob set (the tuning knobs are read once per process)"""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, SBM_MATCH_BANDS="4")
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout + r.stderr
