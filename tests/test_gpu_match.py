@@ -3,6 +3,8 @@
 Parity contract: the set of distinct
 (x, y, similarity bits, class_idx, template_id) tuples; additionally the
 pre-dedup multisets must agree, which is stronger."""
+import os
+
 import numpy as np
 import pytest
 
