@@ -129,6 +129,37 @@ SBM_BP_HD uint32_t bitslice_add8(uint32_t (&c)[P], const uint32_t (&x)[8])
     return e;
 }
 
+// The same for 32 slices with ONE ripple: the four groups' eights meet in two more carry-save levels (planes 3 and 4) and
+// only the resulting thirty-twos ripple up -- 4 x 14 + 6 + 2 (P - 5) instructions instead of 4 x (14 + 2 (P - 3)); what
+// the large-template launches (P = 10, 13) are made of.  Needs P >= 6.
+template <int P>
+SBM_BP_HD uint32_t bitslice_add32(uint32_t (&c)[P], const uint32_t (&x)[32])
+{
+    uint32_t e[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint32_t t0, t1, f0, f1;
+        SBM_CSA(t0, c[0], c[0], x[8 * g + 0], x[8 * g + 1]);
+        SBM_CSA(t1, c[0], c[0], x[8 * g + 2], x[8 * g + 3]);
+        SBM_CSA(f0, c[1], c[1], t0, t1);
+        SBM_CSA(t0, c[0], c[0], x[8 * g + 4], x[8 * g + 5]);
+        SBM_CSA(t1, c[0], c[0], x[8 * g + 6], x[8 * g + 7]);
+        SBM_CSA(f1, c[1], c[1], t0, t1);
+        SBM_CSA(e[g], c[2], c[2], f0, f1);
+    }
+    uint32_t sa, sb, q;
+    SBM_CSA(sa, c[3], c[3], e[0], e[1]);
+    SBM_CSA(sb, c[3], c[3], e[2], e[3]);
+    SBM_CSA(q, c[4], c[4], sa, sb);
+#pragma unroll
+    for (int p = 5; p < P; ++p) { // ripple the thirty-twos
+        const uint32_t t = c[p] & q;
+        c[p] ^= q;
+        q = t;
+    }
+    return q;
+}
+
 // counter of bit position b
 template <int P>
 SBM_BP_HD int bitslice_get(const uint32_t (&c)[P], int b)

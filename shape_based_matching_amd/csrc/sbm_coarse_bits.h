@@ -100,11 +100,12 @@ __device__ __forceinline__ bool bit_pass(const uint32_t* __restrict__ ub, uint32
                 lo[k][DW - 1] = v2.y;
             }
         }
+        constexpr int G = N == 32 ? 32 : 8; // slices per counter update (32: one ripple for four groups of eight)
 #pragma unroll
-        for (int h = 0; h < N; h += 8) {
-            uint32_t x[DW][8];
+        for (int h = 0; h < N; h += G) {
+            uint32_t x[DW][G];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < G; ++k) {
                 // the dword after the lane's own = lane i+1's first (wave_shl:1; lane 63 reads 0 -- it owns no position)
                 const uint32_t nx = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo[h + k][0], 0x130, 0xf, 0xf, true);
 #pragma unroll
@@ -116,7 +117,9 @@ __device__ __forceinline__ bool bit_pass(const uint32_t* __restrict__ ub, uint32
             }
 #pragma unroll
             for (int w = 0; w < DW; ++w) {
-                const uint32_t carry = bitslice_add8<P>(c[w], x[w]);
+                uint32_t carry;
+                if constexpr (G == 32) carry = bitslice_add32<P>(c[w], x[w]);
+                else carry = bitslice_add8<P>(c[w], x[w]);
                 if (MISSES) dead[w] |= carry;
             }
         }
@@ -132,7 +135,14 @@ __device__ __forceinline__ bool bit_pass(const uint32_t* __restrict__ ub, uint32
         // pass A: two batches of 8 first (most items end there: empty background dies after M + 1 <= 8 misses), then 16s --
         // twice the loads in flight for the items that go on; pass B never stops early: 16s throughout
         const int left = nf - g;
-        if (!WIDE || (MISSES && g < 16) || left <= 8) {
+        // thousands of features (P >= 10, one dword per lane): 32 per batch once 32 are in -- 32 loads in flight and one
+        // counter ripple per 32 features; the aliveness test then runs every 32 features (a few per cent of such an item)
+        constexpr bool DEEP = WIDE && P >= 10 && DW == 1;
+        if (DEEP && g >= 32 && left > 16) {
+            if (left >= 32) batch(g, std::integral_constant<int, 32>{}, std::false_type{});
+            else batch(g, std::integral_constant<int, 32>{}, std::true_type{});
+            g += 32;
+        } else if (!WIDE || (MISSES && g < 16) || left <= 8) {
             if (left >= 8) batch(g, std::integral_constant<int, 8>{}, std::false_type{});
             else batch(g, std::integral_constant<int, 8>{}, std::true_type{});
             g += 8;

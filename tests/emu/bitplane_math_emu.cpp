@@ -20,7 +20,32 @@ static uint32_t count(const uint32_t* x, int n, int bias, int32_t* counts)
     return dead;
 }
 
+template <int P>
+static uint32_t count32(const uint32_t* x, int n, int bias, int32_t* counts)
+{
+    uint32_t c[P];
+    for (int p = 0; p < P; ++p) c[p] = (bias >> p) & 1 ? ~0u : 0u;
+    uint32_t dead = 0;
+    for (int g = 0; g < n; g += 32) {
+        uint32_t b32[32];
+        for (int k = 0; k < 32; ++k) b32[k] = x[g + k];
+        dead |= sbm::bitslice_add32<P>(c, b32);
+    }
+    for (int b = 0; b < 32; ++b) counts[b] = sbm::bitslice_get<P>(c, b);
+    return dead;
+}
+
 extern "C" {
+// the 32-slice form (one ripple per 32 slices); n % 32 == 0
+uint32_t sbm_emu_bitslice_count32(const uint32_t* x, int n, int P, int bias, int32_t* counts)
+{
+    switch (P) {
+    case 7: return count32<7>(x, n, bias, counts);
+    case 10: return count32<10>(x, n, bias, counts);
+    case 13: return count32<13>(x, n, bias, counts);
+    default: return 0;
+    }
+}
 
 // 32 spread bytes (cells 0..31) -> out[o] = bit o of every cell, cell b at bit b
 void sbm_emu_bytes32_to_bitplanes(const uint8_t* cells, uint32_t* out)

@@ -23,6 +23,8 @@ def emu():
     L.sbm_emu_bytes32_to_bitplanes.argtypes = [C.c_void_p, C.c_void_p]
     L.sbm_emu_bitslice_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.sbm_emu_bitslice_count.restype = C.c_uint32
+    L.sbm_emu_bitslice_count32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.sbm_emu_bitslice_count32.restype = C.c_uint32
     return L
 
 
@@ -56,3 +58,7 @@ def test_bitsliced_counters_and_sticky_overflow(emu, P):
             # the sticky carry = "the counter passed 2^P at some point" = bias + count >= 2^P (counts only grow)
             want_dead = sum(1 << b for b in range(32) if bias + total[b] >= (1 << P))
             assert dead == want_dead, (n, density, bias)
+            if P >= 7 and n % 32 == 0:  # the 32-slice form (one ripple per 32 slices) counts the same
+                counts32 = np.zeros(32, np.int32)
+                dead32 = emu.sbm_emu_bitslice_count32(x.ctypes.data, n, P, bias, counts32.ctypes.data)
+                assert np.array_equal(counts32, counts) and dead32 == want_dead, (n, density, bias)
