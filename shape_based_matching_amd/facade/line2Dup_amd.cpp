@@ -431,7 +431,9 @@ int acquire_lane(line2Dup::Detector::Engine& e, int want = -1)
                     e.lanes[i]->busy = true;
                     return (int)i;
                 }
-            if ((int)e.lanes.size() < e.max_lanes) {
+            // a batch in flight (matchAsync ... wait) holds its lane between two calls of the SAME thread: it does not count
+            // against the limit, or `matchAsync(); match(); wait();` with setConcurrency(1) would wait for itself
+            if ((int)e.lanes.size() < e.max_lanes + (e.async.active && e.async.lane >= 0 ? 1 : 0)) {
                 e.lanes.emplace_back(new line2Dup::Detector::Engine::Lane);
                 e.lanes.back()->busy = true;
                 return (int)e.lanes.size() - 1;
