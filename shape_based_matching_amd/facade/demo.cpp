@@ -257,6 +257,18 @@ int main(int argc, char** argv)
                 ok_async = ok_async && same(async[f], single[f]);
                 total += single[f].size();
             }
+            // a match() between matchAsync() and wait() on a detector limited to ONE concurrent call: the batch in flight keeps
+            // its lane, the call in between gets another
+            int ok_inter = 1;
+            {
+                line2Dup::Detector one(num_features, {4, 8});
+                one.readClasses(ids, fmt);
+                one.setConcurrency(1);
+                one.matchAsync(frames, threshold, ids);
+                ok_inter = same(one.match(frames[0], threshold, ids), single[0]);
+                const auto w = one.wait();
+                for (size_t f = 0; f < single.size(); ++f) ok_inter = ok_inter && w.size() == single.size() && same(w[f], single[f]);
+            }
             // several contexts in one process: match() shards the templates, matchBatch() deals the frames
             line2Dup::Detector multi(num_features, {4, 8});
             multi.readClasses(ids, fmt);
@@ -269,8 +281,8 @@ int main(int argc, char** argv)
             const auto none = detector.matchBatch(frames, threshold, {std::string("no_such_class")});
             int ok_none = none.size() == frames.size();
             for (const auto& l : none) ok_none = ok_none && l.empty();
-            printf("batch frames %d matches %zu batch_same %d async_same %d devices %zu devices_same %d devices_batch_same %d unknown_class_empty %d\n", nf,
-                   total, ok_batch, ok_async, devices.size(), ok_dev, ok_dev_batch, ok_none);
+            printf("batch frames %d matches %zu batch_same %d async_same %d devices %zu devices_same %d devices_batch_same %d unknown_class_empty %d async_interleaved_same %d\n", nf,
+                   total, ok_batch, ok_async, devices.size(), ok_dev, ok_dev_batch, ok_none, ok_inter);
             for (const auto& m : single[0]) {
                 uint32_t bits;
                 memcpy(&bits, &m.similarity, 4);

@@ -215,7 +215,7 @@ def test_facade_batch_async_and_devices(tmp_path, oracle, case1):
         head = lines[0].split()
         flags = dict(zip(head[1::2], head[2::2]))
         assert flags["frames"] == str(nf) and int(flags["matches"]) > 0
-        for k in ("batch_same", "async_same", "devices_same", "devices_batch_same", "unknown_class_empty"):
+        for k in ("batch_same", "async_same", "devices_same", "devices_batch_same", "unknown_class_empty", "async_interleaved_same"):
             assert flags[k] == "1", (k, lines[0])
         got = [tuple(l.split()) for l in lines[1:]]
         got = [(int(a), int(b), int(c), d, int(e)) for a, b, c, d, e in got]
