@@ -850,6 +850,7 @@ def main():
             "launch": launch,
             "exchange": exchange_path[0],
             "n_ranks_seen": n_ranks_seen,
+            "hip_runtime": capi.HIP_RUNTIME,  # the process's ONE HIP runtime: "system" or torch's bundled copy (capi.py)
             ("ms_per_step_one_frame_at_a_time" if B == 1 else "ms_per_step_one_batch_at_a_time"): single_ms,
             # SURVEY 8d's two times per frame, from the per-kernel pass (kernels alone on one stream):
             # t_match = all kernels, t_templ = the template loop (coarse + refinement) only

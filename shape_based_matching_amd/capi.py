@@ -84,8 +84,50 @@ def _one_hip_runtime_per_process() -> str:
     rt = os.path.join(base, "lib", "libamdhip64.so")
     if not os.path.exists(rt):
         return "system"
+    # Only a runtime of the SONAME libsbm_hip.so was linked against may stand in for it: another SONAME would still give
+    # two runtimes, and mapping it would be pointless.  Both names are read from the ELF dynamic sections.
+    want = [n for n in _elf_dynamic_strings(LIB_PATH, 1) if n.startswith("libamdhip64")]   # DT_NEEDED
+    have = _elf_dynamic_strings(rt, 14)                                                      # DT_SONAME
+    if want and have and have[0] not in want:
+        import warnings
+
+        warnings.warn(f"torch bundles {have[0]} but libsbm_hip.so needs {want[0]}: keeping the system HIP runtime "
+                      "(import torch before creating a context, or expect two runtimes in this process)")
+        return "system"
     C.CDLL(rt, mode=C.RTLD_GLOBAL)
     return rt
+
+
+def _elf_dynamic_strings(path: str, tag: int):
+    """the strings of the ELF64 little-endian dynamic entries with this tag (1 = DT_NEEDED, 14 = DT_SONAME); [] on any surprise"""
+    import struct
+
+    try:
+        with open(path, "rb") as f:
+            data = f.read()
+        if data[:6] != b"\x7fELF\x02\x01":
+            return []
+        shoff, = struct.unpack_from("<Q", data, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+        out = []
+        for sec in secs:
+            if sec[1] != 6:  # SHT_DYNAMIC
+                continue
+            strtab = secs[sec[6]]  # sh_link
+            for off in range(sec[4], sec[4] + sec[5], 16):
+                t, v = struct.unpack_from("<qQ", data, off)
+                if t == 0:
+                    break
+                if t == tag:
+                    s0 = strtab[4] + v
+                    out.append(data[s0:data.index(b"\0", s0)].decode())
+        return out
+    except Exception:
+        return []
+
+
+HIP_RUNTIME = None  # which HIP runtime lib() made the process's one: "system" or the path of torch's copy
 
 
 def lib() -> C.CDLL:
@@ -98,7 +140,8 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} is missing: the HIP extension is not built (run __graft_entry__.build()); "
             "shape_based_matching_amd has no CPU fallback"
         )
-    _one_hip_runtime_per_process()
+    global HIP_RUNTIME
+    HIP_RUNTIME = _one_hip_runtime_per_process()
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     L.sbm_last_error.restype = C.c_char_p

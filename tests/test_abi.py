@@ -56,3 +56,17 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("the oracle", "").replace("with the oracle", ""), os.path.join(dirpath, f)
+
+
+def test_hip_runtime_choice_is_checked_by_soname():
+    """capi maps torch's bundled HIP runtime before libsbm_hip.so only when its SONAME is the one libsbm_hip.so was linked
+    against, and records the choice"""
+    import importlib.util
+
+    needed = [n for n in capi._elf_dynamic_strings(capi.LIB_PATH, 1) if n.startswith("libamdhip64")]
+    assert len(needed) == 1 and needed[0].startswith("libamdhip64.so.")
+    capi.lib()
+    assert capi.HIP_RUNTIME is not None
+    spec = importlib.util.find_spec("torch")
+    if spec is not None and capi.HIP_RUNTIME != "system":
+        assert capi._elf_dynamic_strings(capi.HIP_RUNTIME, 14) == needed
