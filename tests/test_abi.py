@@ -63,6 +63,8 @@ def test_hip_runtime_choice_is_checked_by_soname():
     against, and records the choice"""
     import importlib.util
 
+    from shape_based_matching_amd import capi
+
     needed = [n for n in capi._elf_dynamic_strings(capi.LIB_PATH, 1) if n.startswith("libamdhip64")]
     assert len(needed) == 1 and needed[0].startswith("libamdhip64.so.")
     capi.lib()
