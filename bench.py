@@ -238,17 +238,31 @@ def spawn_ranks(n_gpus):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     print(f"[bench] spawned {n_gpus} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}", file=sys.stderr, flush=True)
-    out0 = procs[0].stdout.read()  # until rank 0 closes its stdout (it exits)
-    rcs = []
-    deadline = time.time() + 120.0  # rank 0 is gone: the others follow at once, or something is wrong with them
-    for r, p in enumerate(procs):
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()  # exactly the process we started
-            rcs.append(p.wait())
-            print(f"[bench] rank {r} (pid {p.pid}) did not exit with rank 0: killed", file=sys.stderr)
-    sys.stdout.buffer.write(out0)
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)  # until rank 0 closes its stdout
+    reader.start()
+    # A rank that dies early (no GPU, a failed communicator) leaves the others waiting in a rendezvous or a collective for
+    # minutes: once any rank has exited with an error the rest get a short grace period and are then killed -- exactly the
+    # processes started here, by pid
+    rcs = [None] * n_gpus
+    failed_at = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and failed_at is None:
+                    failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > 20.0:
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.kill()
+                    rcs[r] = p.wait()
+                    print(f"[bench] rank {r} (pid {p.pid}) was still running 20 s after another rank failed: killed", file=sys.stderr)
+        time.sleep(0.05)
+    reader.join(timeout=5.0)
+    sys.stdout.buffer.write(out0[0] if out0 else b"")
     sys.stdout.flush()
     print(f"[bench] rank exit codes: {rcs}", file=sys.stderr, flush=True)
     return next((rc if 0 < rc < 256 else 1 for rc in rcs if rc != 0), 0)
@@ -298,6 +312,11 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))  # no launcher around us: this process only starts the ranks and forwards rank 0's line
+    if os.environ.get("SBM_BENCH_SELFTEST") == "rank1_fails_rank0_waits" and os.environ.get("SBM_BENCH_SPAWNED"):
+        # test hook of the launcher's supervision (tests/test_bench_spawn.py): no GPU work at all
+        if os.environ.get("RANK") == "1":
+            raise SystemExit(3)
+        time.sleep(300)
     if args.steps is None:
         args.steps = {"case1": 1000, "c3": 200, "c4": 10, "c5": 50}[args.config]
     if args.warmup is None:

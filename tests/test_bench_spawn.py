@@ -40,3 +40,15 @@ def test_single_gpu_call_runs_in_process():
     assert r.returncode != 0
     assert "spawned" not in r.stderr
     assert "bench.py rank 0 of 1: needs an MI355X: no GPU visible" in r.stderr
+
+
+def test_a_rank_that_dies_does_not_leave_the_others_waiting():
+    """one rank exits with an error while another would wait (in a rendezvous, a collective) for minutes: the launcher kills
+    what it started after a grace period and hands back the failing rank's code"""
+    import time
+
+    t0 = time.time()
+    r = run_bench(["--gpus", "2"], {"SBM_BENCH_SELFTEST": "rank1_fails_rank0_waits"}, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert "was still running 20 s after another rank failed: killed" in r.stderr
+    assert 15 < time.time() - t0 < 90
