@@ -265,7 +265,8 @@ def spawn_ranks(n_gpus):
     sys.stdout.buffer.write(out0[0] if out0 else b"")
     sys.stdout.flush()
     print(f"[bench] rank exit codes: {rcs}", file=sys.stderr, flush=True)
-    return next((rc if 0 < rc < 256 else 1 for rc in rcs if rc != 0), 0)
+    # the code of a rank that failed by itself, if any; 1 if ranks only died by signal; 0 if all succeeded
+    return next((rc for rc in rcs if 0 < rc < 256), 1 if any(rc != 0 for rc in rcs) else 0)
 
 
 def main():
