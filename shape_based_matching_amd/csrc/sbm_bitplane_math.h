@@ -98,28 +98,47 @@ void bytes32_to_bitplanes(uint32_t (&d)[8])
 }
 
 // (2) Bit-sliced counters of the coarse pass on bit planes (sbm_coarse_bits.h): c[p] holds bit p of 32 independent counters
-// (one per bit position).  Full adder on 32 slices: (h, l) = a + b + c; the compiler turns each line into one
-// v_bitop3_b32 on gfx950.
-#define SBM_CSA(h, l, a, b, c)                       \
-    do {                                             \
-        const uint32_t u_ = (a) ^ (b);               \
-        (h) = (u_ & (c)) | (~u_ & (a));              \
-        (l) = u_ ^ (c);                              \
-    } while (0)
+// (one per bit position).  Full adder on 32 slices: (h, l) = a + b + c = two v_bitop3_b32 on gfx950 (any function of three
+// inputs is one instruction: parity 0x96, majority 0xe8; truth-table index = S0 * 4 + S1 * 2 + S2).  INV: b and c are to be
+// counted INVERTED (the any-plane's zero bits are the misses) -- parity is unchanged by two inversions, and
+// "majority of (a, ~b, ~c)" is table 0x71, so the inversion costs nothing.  The device pass writes the instruction itself
+// (left to its own pattern matching the compiler builds a full adder from 3 - 4 instructions); the host pass (tests/emu) is C.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SBM_BITOP3(d, s0, s1, s2, tbl) asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:" tbl : "=v"(d) : "v"(s0), "v"(s1), "v"(s2))
+template <bool INV>
+__device__ __forceinline__ void bitslice_csa(uint32_t& h, uint32_t& l, uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t hh, ll;
+    if (INV) SBM_BITOP3(hh, a, b, c, "0x71");
+    else SBM_BITOP3(hh, a, b, c, "0xe8");
+    SBM_BITOP3(ll, a, b, c, "0x96");
+    h = hh;
+    l = ll;
+}
+#else
+template <bool INV>
+inline void bitslice_csa(uint32_t& h, uint32_t& l, uint32_t a, uint32_t b, uint32_t c)
+{
+    if (INV) b = ~b, c = ~c;
+    const uint32_t hh = (a & b) | (a & c) | (b & c), ll = a ^ b ^ c;
+    h = hh;
+    l = ll;
+}
+#endif
 
-// add eight 1-bit slices x[0..7] to the counters c[0..P-1] (Harley-Seal: 7 full adders, then the eights ripple up);
-// returns the carry out of the top plane
-template <int P>
+// add eight 1-bit slices x[0..7] (INV: their complements) to the counters c[0..P-1] (Harley-Seal: 7 full adders, then the
+// eights ripple up); returns the carry out of the top plane
+template <int P, bool INV = false>
 SBM_BP_HD uint32_t bitslice_add8(uint32_t (&c)[P], const uint32_t (&x)[8])
 {
     uint32_t t0, t1, f0, f1, e;
-    SBM_CSA(t0, c[0], c[0], x[0], x[1]);
-    SBM_CSA(t1, c[0], c[0], x[2], x[3]);
-    SBM_CSA(f0, c[1], c[1], t0, t1);
-    SBM_CSA(t0, c[0], c[0], x[4], x[5]);
-    SBM_CSA(t1, c[0], c[0], x[6], x[7]);
-    SBM_CSA(f1, c[1], c[1], t0, t1);
-    SBM_CSA(e, c[2], c[2], f0, f1);
+    bitslice_csa<INV>(t0, c[0], c[0], x[0], x[1]);
+    bitslice_csa<INV>(t1, c[0], c[0], x[2], x[3]);
+    bitslice_csa<false>(f0, c[1], c[1], t0, t1);
+    bitslice_csa<INV>(t0, c[0], c[0], x[4], x[5]);
+    bitslice_csa<INV>(t1, c[0], c[0], x[6], x[7]);
+    bitslice_csa<false>(f1, c[1], c[1], t0, t1);
+    bitslice_csa<false>(e, c[2], c[2], f0, f1);
 #pragma unroll
     for (int p = 3; p < P; ++p) { // ripple the eights
         const uint32_t t = c[p] & e;
@@ -132,25 +151,25 @@ SBM_BP_HD uint32_t bitslice_add8(uint32_t (&c)[P], const uint32_t (&x)[8])
 // The same for 32 slices with ONE ripple: the four groups' eights meet in two more carry-save levels (planes 3 and 4) and
 // only the resulting thirty-twos ripple up -- 4 x 14 + 6 + 2 (P - 5) instructions instead of 4 x (14 + 2 (P - 3)); what
 // the large-template launches (P = 10, 13) are made of.  Needs P >= 6.
-template <int P>
+template <int P, bool INV = false>
 SBM_BP_HD uint32_t bitslice_add32(uint32_t (&c)[P], const uint32_t (&x)[32])
 {
     uint32_t e[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         uint32_t t0, t1, f0, f1;
-        SBM_CSA(t0, c[0], c[0], x[8 * g + 0], x[8 * g + 1]);
-        SBM_CSA(t1, c[0], c[0], x[8 * g + 2], x[8 * g + 3]);
-        SBM_CSA(f0, c[1], c[1], t0, t1);
-        SBM_CSA(t0, c[0], c[0], x[8 * g + 4], x[8 * g + 5]);
-        SBM_CSA(t1, c[0], c[0], x[8 * g + 6], x[8 * g + 7]);
-        SBM_CSA(f1, c[1], c[1], t0, t1);
-        SBM_CSA(e[g], c[2], c[2], f0, f1);
+        bitslice_csa<INV>(t0, c[0], c[0], x[8 * g + 0], x[8 * g + 1]);
+        bitslice_csa<INV>(t1, c[0], c[0], x[8 * g + 2], x[8 * g + 3]);
+        bitslice_csa<false>(f0, c[1], c[1], t0, t1);
+        bitslice_csa<INV>(t0, c[0], c[0], x[8 * g + 4], x[8 * g + 5]);
+        bitslice_csa<INV>(t1, c[0], c[0], x[8 * g + 6], x[8 * g + 7]);
+        bitslice_csa<false>(f1, c[1], c[1], t0, t1);
+        bitslice_csa<false>(e[g], c[2], c[2], f0, f1);
     }
     uint32_t sa, sb, q;
-    SBM_CSA(sa, c[3], c[3], e[0], e[1]);
-    SBM_CSA(sb, c[3], c[3], e[2], e[3]);
-    SBM_CSA(q, c[4], c[4], sa, sb);
+    bitslice_csa<false>(sa, c[3], c[3], e[0], e[1]);
+    bitslice_csa<false>(sb, c[3], c[3], e[2], e[3]);
+    bitslice_csa<false>(q, c[4], c[4], sa, sb);
 #pragma unroll
     for (int p = 5; p < P; ++p) { // ripple the thirty-twos
         const uint32_t t = c[p] & q;

@@ -111,15 +111,15 @@ __device__ __forceinline__ bool bit_pass(const uint32_t* __restrict__ ub, uint32
 #pragma unroll
                 for (int w = 0; w < DW; ++w) {
                     const uint32_t v = __builtin_amdgcn_alignbit(w + 1 < DW ? lo[h + k][w + 1] : nx, lo[h + k][w], (uint32_t)sh[h + k]);
-                    x[w][k] = MISSES ? ~v : v;
-                    if (TAIL && g + h + k >= nf) x[w][k] = 0u; // wave-uniform
+                    x[w][k] = v; // pass A counts the ZERO bits: the inversion is folded into the adders' truth tables
+                    if (TAIL && g + h + k >= nf) x[w][k] = MISSES ? ~0u : 0u; // padding counts nothing (wave-uniform)
                 }
             }
 #pragma unroll
             for (int w = 0; w < DW; ++w) {
                 uint32_t carry;
-                if constexpr (G == 32) carry = bitslice_add32<P>(c[w], x[w]);
-                else carry = bitslice_add8<P>(c[w], x[w]);
+                if constexpr (G == 32) carry = bitslice_add32<P, MISSES>(c[w], x[w]);
+                else carry = bitslice_add8<P, MISSES>(c[w], x[w]);
                 if (MISSES) dead[w] |= carry;
             }
         }

@@ -21,9 +21,9 @@ def emu():
     subprocess.check_call(["make", "-s", "-C", EMU_DIR])
     L = C.CDLL(os.path.join(EMU_DIR, "libsbm_emu.so"))
     L.sbm_emu_bytes32_to_bitplanes.argtypes = [C.c_void_p, C.c_void_p]
-    L.sbm_emu_bitslice_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.sbm_emu_bitslice_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.sbm_emu_bitslice_count.restype = C.c_uint32
-    L.sbm_emu_bitslice_count32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.sbm_emu_bitslice_count32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.sbm_emu_bitslice_count32.restype = C.c_uint32
     return L
 
@@ -53,12 +53,17 @@ def test_bitsliced_counters_and_sticky_overflow(emu, P):
         total = bits.sum(axis=0)
         for bias in (0, 1, (1 << P) - 1, rs.randint(0, 1 << P)):
             counts = np.zeros(32, np.int32)
-            dead = emu.sbm_emu_bitslice_count(x.ctypes.data, n, P, bias, counts.ctypes.data)
+            dead = emu.sbm_emu_bitslice_count(x.ctypes.data, n, P, bias, counts.ctypes.data, 0)
             assert np.array_equal(counts, (bias + total) % (1 << P))
             # the sticky carry = "the counter passed 2^P at some point" = bias + count >= 2^P (counts only grow)
             want_dead = sum(1 << b for b in range(32) if bias + total[b] >= (1 << P))
             assert dead == want_dead, (n, density, bias)
             if P >= 7 and n % 32 == 0:  # the 32-slice form (one ripple per 32 slices) counts the same
                 counts32 = np.zeros(32, np.int32)
-                dead32 = emu.sbm_emu_bitslice_count32(x.ctypes.data, n, P, bias, counts32.ctypes.data)
+                dead32 = emu.sbm_emu_bitslice_count32(x.ctypes.data, n, P, bias, counts32.ctypes.data, 0)
                 assert np.array_equal(counts32, counts) and dead32 == want_dead, (n, density, bias)
+            # inverted-input form: the zero bits of the complemented slices are the same set
+            xi = ~x
+            ci = np.zeros(32, np.int32)
+            di = emu.sbm_emu_bitslice_count(xi.ctypes.data, n, P, bias, ci.ctypes.data, 1)
+            assert np.array_equal(ci, counts) and di == want_dead, (n, density, bias)
