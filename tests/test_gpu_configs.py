@@ -102,6 +102,31 @@ def test_config3_config4_full_size_properties(ctx_factory, cfg, first, count, n_
     assert sorted(union) == whole
 
 
+@pytest.mark.parametrize("cfg,first,count", [(C3, 0, 3600), (C4, 4500, 4500), (C4, 0, 36000)],
+                         ids=["c3-all-3600", "c4-one-rank-share-4500", "c4-all-36000"])
+def test_config3_full_and_config4_rank_share_against_the_oracle(oracle, ctx_factory, cfg, first, count):
+    """Round 4 (the full-size checks were self-comparisons): BASELINE config 3 at its FULL stated
+    size -- all 3600 templates on 2048^2 maps -- and config 4 at the size one rank of the 8-GPU job runs it -- 4 500 templates
+    x 8191 / 4095 features on 4096^2 maps --, and config 4 at its FULL stated size, all 36 000 templates (442 M features),
+    against the ORACLE's template loop on the box's host cores (the 16-thread oracle needs a few seconds for the first two,
+    under a minute for the last): match multiset and the coarse pass's algorithmic byte count, bit for bit.  Inputs are
+    the bench's (synth.stage_b_fixed, seed 1234)."""
+    T = (4, 8)
+    side, n_total, nf, box, n_plants = cfg
+    maps, ts = synth.stage_b_fixed(1234, side, side, T, n_total, nf, templ_size=box, n_plants=n_plants, first=first, count=count)
+    ctx = ctx_factory(T=T, max_candidates=1 << 22)
+    ctx.upload_templates(ts)
+    for l in range(2):
+        ctx.set_quantized(l, maps[l])
+    got = ctx.match_templates(90.0)
+    pyr = oracle.Pyramid.from_quantized(maps, T)
+    want = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 90.0, n_threads=min(16, os.cpu_count() or 1))
+    assert len(want) > 0
+    assert multiset(got) == multiset(want)
+    assert ctx.coarse_bytes() == pyr.coarse_bytes(ts.levels, ts.features)
+    pyr.free()
+
+
 def test_config5_one_frame_all_templates(oracle, ctx_factory):
     """1920 x 1072 (the 1080p frame cropped to multiples of 16, test.cpp:349-353), 1000 templates x 128 / 64"""
     run_stage_b(oracle, ctx_factory, 1072, 1920, 1000, [128, 64], 260, plant_every=40)
@@ -221,6 +246,15 @@ def test_config5_full_size_properties(ctx_factory, case1):
         return sorted((r[0] - shift, r[1], r[3], r[4], r[5]) for r in recs if 400 + shift <= r[0] < cols - 700 + shift)
 
     assert interior(whole[0], 0) == interior(whole[2], 16) and len(interior(whole[0], 0)) > 0
+    # Round 4: and against the ORACLE, every one of the 64 frames x 1000 templates -- the whole
+    # configuration at its stated size, not a sample (the 16-thread oracle needs about 0.1 s per frame)
+    from oracle import oracle as O
+
+    for b in range(B):
+        pyr = O.Pyramid.build(frames[b], [4, 8], 30.0)
+        want = pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, thr, n_threads=min(16, os.cpu_count() or 1))
+        pyr.free()
+        assert key(want) == whole[b], b
 
 
 def key(recs):
