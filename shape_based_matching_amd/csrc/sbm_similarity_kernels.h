@@ -833,7 +833,9 @@ __device__ __forceinline__ void accumulate_rows16_q(const uint8_t* __restrict__ 
 // LOCAL_WAVES waves each take a contiguous slice of the features and the partial
 // sums meet in LDS.  Result (packed u16) valid in wave 0.
 constexpr int LOCAL_WAVES = 16;
-template <int COMPACT = 0, int LW = LOCAL_WAVES>
+// T8: the strip path's stride (COMPACT == 2: T = 4 or 8, a template parameter of its inner loop) -- a launch instantiates
+// only its own (half the code of the kernel, which is what its waves have to keep in the instruction cache)
+template <int COMPACT = 0, int LW = LOCAL_WAVES, bool T8 = false>
 __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int64_t lm_stride, const DevTL tl,
                                             const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
                                             int rows, int cols, int W, int H, int T, int ox, int oy,
@@ -857,8 +859,8 @@ __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int6
             else if (q == 2) accumulate_rows16_q<LOG2T_, 2, LW / 4>(lm, fx, fl, cls, part, rows, cols, ox, oy, W, H, l4, h4); \
             else accumulate_rows16_q<LOG2T_, 3, LW / 4>(lm, fx, fl, cls, part, rows, cols, ox, oy, W, H, l4, h4);             \
         } while (0)
-        if (T == 4) SBM_ROWS16(2);
-        else SBM_ROWS16(3);
+        if (T8) SBM_ROWS16(3);
+        else SBM_ROWS16(2);
 #undef SBM_ROWS16
         // the four feature slots of the wave (lanes r, r+16, r+32, r+48), then the waves of the workgroup; the last
         // read also turns (row, 16 columns) per lane into the (row, 4 columns) per lane the caller scans
@@ -924,7 +926,7 @@ __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int6
 //      and a third arrival level: config 5 (64 frames, ~1400 candidates each) 1878 -> 1753 us per step, but 16 tiled
 //      1024^2 frames 200 -> 207 us (tools/r03_local_order.sh), so the host picks by the planes' total size.
 //   (the frame as the SLOW dimension of order 0's grid was measured too: between the two on config 5, 1825 us)
-template <int COMPACT, int LW, int ORDER>
+template <int COMPACT, int LW, int ORDER, bool T8 = false>
 __global__ __launch_bounds__(64 * LW) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_similarity_local(
     const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int l,
     const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
@@ -996,7 +998,7 @@ __global__ __launch_bounds__(64 * LW) __attribute__((amdgpu_waves_per_eu(6, 6)))
         y = y > max_y ? max_y : y;
         const int ox = (x / T - 8) * T, oy = (y / T - 8) * T;
         uint32_t lo, hi;
-        local_patch<COMPACT, LW>(lm + frame * lm_fs, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi, flabel,
+        local_patch<COMPACT, LW, T8>(lm + frame * lm_fs, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi, flabel,
                                  COMPACT == 2 ? fcls + ((size_t)c.t * L + l) * 17 : nullptr);
         if (wave != 0) continue;
         // first maximum in row-major order, strict '>' from 0 (:1265-1282): maximise (raw, -position)
