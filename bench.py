@@ -577,9 +577,12 @@ def main():
             sl.ctx.set_graph_mode(False)  # the library's default with several batches in flight is replay: opt out for the A/B
         t_stream = probe()
         issue_stream = last_issue_s[0] / 40 * 1e6
+        # a context keeps 16 captured graphs (one per argument tuple = input buffer here): a longer ring of input buffers
+        # would evict and re-capture on every step, so replay is not a candidate then
+        graph_ok = len(ring) <= 16
         for sl in slots:
-            sl.ctx.set_graph_mode(True)
-        t_graph = probe()
+            sl.ctx.set_graph_mode(graph_ok)
+        t_graph = probe() if graph_ok else float("inf")
         launch["probe_us_per_step"] = {"stream launches": round(t_stream, 1), "hipGraph replay": round(t_graph, 1)}
         # host time spent inside the launch calls of a step (no synchronisation): tells a slow GPU from a blocking host
         launch["probe_host_enqueue_us_per_step"] = {"stream launches": round(issue_stream, 1),
