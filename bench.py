@@ -583,7 +583,7 @@ def main():
         for sl in slots:
             sl.ctx.set_graph_mode(graph_ok)
         t_graph = probe() if graph_ok else float("inf")
-        launch["probe_us_per_step"] = {"stream launches": round(t_stream, 1), "hipGraph replay": round(t_graph, 1)}
+        launch["probe_us_per_step"] = {"stream launches": round(t_stream, 1), "hipGraph replay": round(t_graph, 1) if graph_ok else None}
         # host time spent inside the launch calls of a step (no synchronisation): tells a slow GPU from a blocking host
         launch["probe_host_enqueue_us_per_step"] = {"stream launches": round(issue_stream, 1),
                                                     "hipGraph replay": round(last_issue_s[0] / 40 * 1e6, 1)}
