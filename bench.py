@@ -805,7 +805,9 @@ def main():
             "k_similarity_coarse": "bit-plane kernel: vector issue of the bit-sliced counters and L2 -> L1 bandwidth of the items still "
                                    "alive on large template sets (c4: both near their ceilings); the longest work items' chain of "
                                    "dependent L2 round trips on a 16-frame case1 launch",
-            "k_similarity_local": "L2 line traffic of the 16x16 patch reads + vector issue of the response LUT",
+            "k_similarity_local": "bit strips (T = 4 levels): what a CU's vector memory path delivers from the L2s for dword gathers "
+                                  "(~11 bytes per clock and CU: 128 bytes per feature and candidate); spread bytes (other levels): L2 line "
+                                  "traffic of the 16x16 patch reads + vector issue of the response LUT",
         }
         for name in kern:
             if name in alg:

@@ -189,6 +189,15 @@ int sbm_set_quantize_mode(sbm_ctx* ctx, int32_t mode, int32_t rows_per_wave);
  * 1: always the four-wave kernel; 2: always the one-wave kernel.  Identical candidates either way; a test / tuning knob. */
 int sbm_set_coarse_mode(sbm_ctx* ctx, int32_t mode);
 
+/* Which form of a refinement level with T = 4 the match entry points build and the refinement pass (similarityLocal(_64),
+ * line2Dup.cpp:860-922, :986-1048) reads.  1: BIT STRIPS -- per (sub-plane, orientation, strip of 16 columns, grid row) one
+ * dword, "response > 0" bits of the 16 cells | "response == 4" bits << 16; the reference's sum of response bytes {0, 3, 4}
+ * is 3 #any + #exact, counted with bit-sliced carry-save counters, one wave per candidate.  0: one plane of spread bytes,
+ * the response looked up per byte (rounds 2-3).  -1 (default): the process default (bit strips unless SBM_LOCAL_BITS=0).
+ * Levels with another T, or whose grid width is not a multiple of 16 cells, use the byte form either way.  Identical
+ * matches; a test / tuning knob. */
+int sbm_set_refine_bits(sbm_ctx* ctx, int32_t mode);
+
 /* Which candidate a workgroup of the refinement pass (similarityLocal(_64) + the loop at line2Dup.cpp:1221-1293) takes.
  * 0: a grid of (frames x slots), every frame's candidates walked by that frame's slots; 2: the candidates of up to 64
  * frames as ONE frame-major list walked by the whole grid (the workgroups running together stay on one or two frames,

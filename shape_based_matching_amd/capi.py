@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "sbm_match_batch_device_banded", "sbm_pin_host_buffer", "sbm_unpin_host_buffer",
     "sbm_select_templates", "sbm_partition_templates", "sbm_match_sharded",
     "sbm_match_batch_host", "sbm_match_batch_host_begin", "sbm_match_batch_host_end", "sbm_extract_local_maxima",
-    "sbm_set_pipeline_depth", "sbm_set_coarse_mode", "sbm_set_refine_order", "sbm_get_coarse_bitplanes",
+    "sbm_set_pipeline_depth", "sbm_set_coarse_mode", "sbm_set_refine_order", "sbm_set_refine_bits", "sbm_get_coarse_bitplanes",
     "sbm_comm_count", "sbm_match_templates_device_sharded", "sbm_graph_count",
 ]
 
@@ -193,6 +193,7 @@ def lib() -> C.CDLL:
     L.sbm_set_pipeline_depth.argtypes = [vp, i32]
     L.sbm_set_coarse_mode.argtypes = [vp, i32]
     L.sbm_set_refine_order.argtypes = [vp, i32]
+    L.sbm_set_refine_bits.argtypes = [vp, i32]
     L.sbm_select_templates.argtypes = [vp, vp, i32]
     L.sbm_partition_templates.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp]
     L.sbm_match_sharded.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, f32, vp, i64, C.POINTER(i64)]
@@ -435,6 +436,10 @@ class Context:
         """coarse-pass kernel: "auto" (bit planes whenever the threshold is >= 0), "block" (bytes, four waves per item), "wave"
         (bytes, one wave per item), "bits", "bytes" (block or wave by launch size); identical candidates"""
         _check(lib().sbm_set_coarse_mode(self._h, {"auto": 0, "": 0, "block": 1, "wave": 2, "bits": 3, "bytes": 4}[mode]))
+
+    def set_refine_bits(self, mode=None):
+        """None: the process default; True: T = 4 refinement levels as bit strips; False: as spread bytes (sbm.h)."""
+        _check(lib().sbm_set_refine_bits(self._h, -1 if mode is None else (1 if mode else 0)))
 
     def set_refine_order(self, order: str = "auto"):
         """refinement pass: "auto" (by the batch's plane size), "slots" (per-frame slots) or "list" (one frame-major list)"""

@@ -179,6 +179,77 @@ SBM_BP_HD uint32_t bitslice_add32(uint32_t (&c)[P], const uint32_t (&x)[32])
     return q;
 }
 
+// four / two slices (the tails of the refinement pass's feature loop, sbm_local_bits.h)
+template <int P>
+SBM_BP_HD void bitslice_add4(uint32_t (&c)[P], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
+{
+    uint32_t t0, t1, e;
+    bitslice_csa<false>(t0, c[0], c[0], x0, x1);
+    bitslice_csa<false>(t1, c[0], c[0], x2, x3);
+    bitslice_csa<false>(e, c[1], c[1], t0, t1);
+#pragma unroll
+    for (int p = 2; p < P; ++p) { // ripple the fours
+        const uint32_t t = c[p] & e;
+        c[p] ^= e;
+        e = t;
+    }
+}
+template <int P>
+SBM_BP_HD void bitslice_add2(uint32_t (&c)[P], uint32_t x0, uint32_t x1)
+{
+    uint32_t e;
+    bitslice_csa<false>(e, c[0], c[0], x0, x1);
+#pragma unroll
+    for (int p = 1; p < P; ++p) { // ripple the twos
+        const uint32_t t = c[p] & e;
+        c[p] ^= e;
+        e = t;
+    }
+}
+
+// a[0..N) += b[0..N) as N-plane numbers; the carry out of plane N-1 goes to a[N] (the caller provides the room)
+template <int N, int PM>
+SBM_BP_HD void bitslice_add_planes(uint32_t (&a)[PM], const uint32_t (&b)[PM])
+{
+    static_assert(N < PM, "room for the carry");
+    uint32_t carry = 0;
+#pragma unroll
+    for (int p = 0; p < N; ++p) bitslice_csa<false>(carry, a[p], a[p], b[p], carry);
+    a[N] = carry;
+}
+
+// Refinement pass on bit strips (sbm_local_bits.h): s[0..N) are the bit-sliced counts of one patch row, "response > 0"
+// counts in bit positions 0..15 (one per column), "response == 4" counts in positions 16..31.  The reference's sum of
+// response bytes (4 / 3 / 0, similarityLocal line2Dup.cpp:860-922) is raw = 3 #any + #exact; returns, for the row, the largest raw
+// (<= 2^(N+2) - 1) and through *first the lowest column holding it.  All in bit-sliced form: raw = A + E + 2A by two plane-wise
+// additions, then the maximum from the top plane down (keep the columns whose bit is set whenever any kept column has it).
+template <int N, int PM>
+SBM_BP_HD uint32_t bitslice_row_best(const uint32_t (&s)[PM], int* first)
+{
+    static_assert(N + 2 <= PM, "room for raw");
+    uint32_t r[PM], e[PM], a2[PM];
+#pragma unroll
+    for (int p = 0; p < PM; ++p) {
+        r[p] = p < N ? s[p] : 0u;
+        e[p] = p < N ? s[p] >> 16 : 0u;
+        a2[p] = p >= 1 && p <= N ? s[p - 1] : 0u;
+    }
+    bitslice_add_planes<N>(r, e);       // A + E: N + 1 planes
+    bitslice_add_planes<N + 1>(r, a2);  // + 2A:  N + 2 planes
+    uint32_t mask = 0xffffu;
+#pragma unroll
+    for (int p = N + 1; p >= 0; --p) {
+        const uint32_t t = mask & r[p];
+        mask = t ? t : mask;
+    }
+    const int f = __builtin_ctz(mask); // mask != 0
+    uint32_t v = 0;
+#pragma unroll
+    for (int p = 0; p < N + 2; ++p) v |= ((r[p] >> f) & 1u) << p;
+    *first = f;
+    return v;
+}
+
 // counter of bit position b
 template <int P>
 SBM_BP_HD int bitslice_get(const uint32_t (&c)[P], int b)

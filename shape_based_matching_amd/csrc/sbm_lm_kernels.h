@@ -286,15 +286,36 @@ __device__ __forceinline__ void build_lm_rows_item(const uint8_t* __restrict__ q
 // prefix ORs of the next three (V_ty = rows[ty..3] | rows[4..3+ty]), and then does per ty what the other form does: OR of
 // T pixels forward, register transpose, LDS hop so that a wave stores one strip (runs of 256 bytes).  A workgroup = 16
 // grid rows x 64 cells x 4 ty; 16 KB of LDS.  7 row loads and ~45 ORs per 16 stored dwords instead of 16 and ~80.
+//
+// BITS (round 4, read by k_similarity_local_bits, sbm_local_bits.h): the level is stored as BIT STRIPS instead -- per
+// (sub-plane, orientation o, strip of 16 columns, grid row) one dword = "response > 0" bits of the 16 cells (spread bits
+// o-1, o, o+1) in the low half, "response == 4" bits (spread bit o) in the high half:
+//     dword index = ((sub * 8 + o) * (W / 16) + strip) * H + gy            (lm_bits_offset; 2 bytes per pixel, zero tail behind)
+// so a feature's 16 x 16 patch is two runs of 64 bytes.  The workgroup is then 32 grid rows x 32 cells (two strips) instead
+// of 16 x 64: its loads and its stores are both runs of 128 bytes.  Measured on the way (16 frames; the byte form's launch
+// is 13.2 us, its refinement of 16 candidate-heavy frames 35): 16-row workgroups, 64-byte store runs 19.2 us; the four
+// strips of a 64-cell group side by side, 256-byte store runs 15.2 -- but the reader's 16 rows then lie in 8 cache lines
+// instead of 2 and its launch goes from 19 to 33 us; strip pairs side by side 17.0 / 23; this form 17.7 / 19.5.
+// After the LDS hop a thread takes two units (sub, strip, row pair): the 32 spread bytes of two strip rows -> 8 bit-plane
+// dwords (bytes32_to_bitplanes) -> 8 stores of 8 bytes.
+__host__ __device__ __forceinline__ int64_t lm_bits_offset(int plane, int strip, int gy, int W, int H)
+{
+    return ((int64_t)plane * (W >> 4) + strip) * H + gy;
+}
+// dwords of a level stored as bit strips, without the zero tail
+__host__ __device__ __forceinline__ int64_t lm_bits_dwords(int W, int H) { return (int64_t)128 * (W >> 4) * H; }
+
+template <bool BITS = false>
 __device__ __forceinline__ void build_lm_strip4_allty(const uint8_t* __restrict__ q, int rows, int cols, int W, int H,
                                                       uint8_t* __restrict__ lm, int64_t blk, uint32_t* s_tile4)
 {
     constexpr int T = 4;
-    const int n_cb = (W + 63) >> 6;
+    constexpr int TR = BITS ? 32 : 16, TK = BITS ? 8 : 16; // tile: grid rows x threads per row (4 cells each)
+    const int n_cb = (W + 4 * TK - 1) / (4 * TK);
     const int t = (int)threadIdx.x;
     const int tile_cb = (int)(blk % n_cb), tile_gyb = (int)(blk / n_cb);
-    const int row = t >> 4, kk = t & 15;
-    const int gy = tile_gyb * 16 + row, k = tile_cb * 16 + kk;
+    const int row = t / TK, kk = t % TK;
+    const int gy = tile_gyb * TR + row, k = tile_cb * TK + kk;
     const bool active = gy < H && k * 4 < W;
     const int c0 = (active ? k : 0) * 16; // first pixel column of this thread's 4 cells
     uint32_t r[7][5];
@@ -335,10 +356,37 @@ __device__ __forceinline__ void build_lm_strip4_allty(const uint8_t* __restrict_
         for (int tx = 0; tx < T; ++tx) {
             const uint32_t p01 = perm_b32(sp[1], sp[0], 0x0c0c0000u | ((4 + tx) << 8) | tx);
             const uint32_t p23 = perm_b32(sp[3], sp[2], 0x00000c0cu | ((4 + tx) << 24) | (tx << 16));
-            s_tile4[(ty * T + tx) * 256 + (kk >> 2) * 64 + row * 4 + (kk & 3)] = p01 | p23;
+            s_tile4[(ty * T + tx) * 256 + (kk >> 2) * (TR * 4) + row * 4 + (kk & 3)] = p01 | p23;
         }
     }
     __syncthreads();
+    if (BITS) {
+        struct __attribute__((aligned(4))) u32x2_a4 { uint32_t x, y; };
+        uint32_t* const lb = (uint32_t*)lm;
+        const int n_strips = W >> 4;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            const int u = pass * 256 + t;
+            const int rp = u & 15, st = (u >> 4) & 1, sub = u >> 5;
+            const int S = tile_cb * 2 + st, gy2 = tile_gyb * 32 + rp * 2;
+            const uint4 lo4 = *(const uint4*)&s_tile4[sub * 256 + st * 128 + rp * 8];
+            const uint4 hi4 = *(const uint4*)&s_tile4[sub * 256 + st * 128 + rp * 8 + 4];
+            uint32_t d[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+            bytes32_to_bitplanes(d); // bit b of d[bitplane_reg(o)]: row gy2 column b (b < 16), row gy2 + 1 column b - 16
+            if (S < n_strips && gy2 < H) {
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    const uint32_t e = d[bitplane_reg(o)];
+                    const uint32_t any = d[bitplane_reg((o + 7) & 7)] | e | d[bitplane_reg((o + 1) & 7)];
+                    const uint32_t w0 = perm_b32(e, any, 0x05040100u), w1 = perm_b32(e, any, 0x07060302u);
+                    uint32_t* dst = lb + lm_bits_offset(sub * 8 + o, S, gy2, W, H);
+                    if (gy2 + 1 < H) *(u32x2_a4*)dst = u32x2_a4{w0, w1};
+                    else *dst = w0;
+                }
+            }
+        }
+        return;
+    }
     const int S = tile_cb * 4 + (t >> 6), gy2 = tile_gyb * 16 + ((t & 63) >> 2);
     if (S < (W >> 4) && gy2 < H) {
 #pragma unroll
@@ -358,7 +406,8 @@ struct LmLevelArgs {
     int64_t q_fs, lm_fs; // bytes from one frame of a batch to the next
     int32_t compact;     // 1: lm is ONE plane [T*T][W*H] of spread bytes (a level that only the refinement pass
                          // reads): 1/8 of the stores and of the HBM write-back; 2: the same plane strip-interleaved;
-                         // 3: lm is the coarsest level's 16 BIT planes (lm_stride bits each; sbm_coarse_bits.h)
+                         // 3: lm is the coarsest level's 16 BIT planes (lm_stride bits each; sbm_coarse_bits.h);
+                         // 4 (with allty): a refinement level as bit strips (build_lm_strip4_allty, sbm_local_bits.h)
     int32_t split;       // 8-plane levels: LM_FULL_SPLIT work items per (pixel row, 4 cells) instead of 1
     int32_t allty;       // compact == 2, T == 4: one thread per (grid row, 4 cells) for all four ty (build_lm_strip4_allty)
 };
@@ -387,7 +436,8 @@ __global__ __launch_bounds__(256) void k_build_lm_rows(const LmArgs a)
     const int64_t item = (int64_t)((int)blockIdx.x - p.block_begin) * 256 + threadIdx.x;
     const uint8_t* q = p.q + frame * p.q_fs;
     uint8_t* lm = p.lm + frame * p.lm_fs;
-    if (p.allty) build_lm_strip4_allty(q, p.rows, p.cols, p.W, p.H, lm, (int64_t)((int)blockIdx.x - p.block_begin), s_tile);
+    if (p.allty && p.compact == 4) build_lm_strip4_allty<true>(q, p.rows, p.cols, p.W, p.H, lm, (int64_t)((int)blockIdx.x - p.block_begin), s_tile);
+    else if (p.allty) build_lm_strip4_allty<false>(q, p.rows, p.cols, p.W, p.H, lm, (int64_t)((int)blockIdx.x - p.block_begin), s_tile);
     else if (p.T == 4) build_lm_rows_item<4>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact, p.split, s_tile);
     else build_lm_rows_item<8>(q, p.rows, p.cols, p.W, p.H, lm, p.lm_stride, item, p.compact, p.split, s_tile);
 }

@@ -9,6 +9,8 @@
 #include "sbm_common.h"
 #include "sbm_lm_kernels.h" // response4: the refinement pass applies the response LUT to spread bytes
 
+#include "sbm_local_bits.h"
+
 namespace sbm {
 
 // ---------------------------------------------------------------------------
@@ -833,6 +835,7 @@ __device__ __forceinline__ void accumulate_rows16_q(const uint8_t* __restrict__ 
 // LOCAL_WAVES waves each take a contiguous slice of the features and the partial
 // sums meet in LDS.  Result (packed u16) valid in wave 0.
 constexpr int LOCAL_WAVES = 16;
+// COMPACT: 0 eight response planes, 1 one plane of spread bytes, 2 the same strip-interleaved, 3 bit strips (LW = 1)
 // T8: the strip path's stride (COMPACT == 2: T = 4 or 8, a template parameter of its inner loop) -- a launch instantiates
 // only its own (half the code of the kernel, which is what its waves have to keep in the instruction cache)
 template <int COMPACT = 0, int LW = LOCAL_WAVES, bool T8 = false>
@@ -926,15 +929,20 @@ __device__ __forceinline__ void local_patch(const uint8_t* __restrict__ lm, int6
 //      and a third arrival level: config 5 (64 frames, ~1400 candidates each) 1878 -> 1753 us per step, but 16 tiled
 //      1024^2 frames 200 -> 207 us (tools/r03_local_order.sh), so the host picks by the planes' total size.
 //   (the frame as the SLOW dimension of order 0's grid was measured too: between the two on config 5, 1825 us)
+#define SBM_LOCAL_PARAMS                                                                                                    \
+    const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int l,              \
+    const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,                     \
+    const int32_t* __restrict__ raw_keep, const int32_t* __restrict__ class_idx,                                           \
+    const int32_t* __restrict__ template_id, Cand* __restrict__ cands, int32_t* __restrict__ counters,                     \
+    int cand_cap, int is_last, sbm_match_rec* __restrict__ out, int32_t* __restrict__ out_count,                           \
+    int out_cap, sbm_match_rec* __restrict__ mirror_out, int32_t* __restrict__ mirror_count, int collect_stats,            \
+    int64_t lm_fs, const uint8_t* __restrict__ flabel, const uint16_t* __restrict__ fcls, int frames
+#define SBM_LOCAL_ARGS                                                                                                      \
+    lm, lm_stride, rows, cols, T, W, H, L, l, tls, fxy, foff, raw_keep, class_idx, template_id, cands, counters, cand_cap,  \
+    is_last, out, out_count, out_cap, mirror_out, mirror_count, collect_stats, lm_fs, flabel, fcls, frames
+
 template <int COMPACT, int LW, int ORDER, bool T8 = false>
-__global__ __launch_bounds__(64 * LW) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_similarity_local(
-    const uint8_t* __restrict__ lm, int64_t lm_stride, int rows, int cols, int T, int W, int H, int L, int l,
-    const DevTL* __restrict__ tls, const uint32_t* __restrict__ fxy, const int32_t* __restrict__ foff,
-    const int32_t* __restrict__ raw_keep, const int32_t* __restrict__ class_idx,
-    const int32_t* __restrict__ template_id, Cand* __restrict__ cands, int32_t* __restrict__ counters,
-    int cand_cap, int is_last, sbm_match_rec* __restrict__ out, int32_t* __restrict__ out_count,
-    int out_cap, sbm_match_rec* __restrict__ mirror_out, int32_t* __restrict__ mirror_count, int collect_stats,
-    int64_t lm_fs, const uint8_t* __restrict__ flabel, const uint16_t* __restrict__ fcls, int frames)
+__device__ __forceinline__ void similarity_local_body(SBM_LOCAL_PARAMS)
 {
     // The refinement pass runs at the gradient kernels' priority when it follows them (a match call: beside other batches'
     // gradient launches its few working workgroups at a raised priority cost more than they gain -- scene frame 111.9 ->
@@ -984,6 +992,13 @@ __global__ __launch_bounds__(64 * LW) __attribute__((amdgpu_waves_per_eu(6, 6)))
         }
         Cand* const cand_p = cands + frame * cand_cap + ci;
         Cand c = ORDER != 2 && g == g_first ? c_first : *cand_p;
+        if constexpr (COMPACT == 3) {
+            // every lane read the same record: said so, the record and what is derived from it (clamps, the template record,
+            // the Match) live in scalar registers across the feature loop instead of being spilled around it
+            int32_t* w = (int32_t*)&c;
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(Cand) / 4); ++i) w[i] = __builtin_amdgcn_readfirstlane(w[i]);
+        }
         if (c.raw < 0) continue; // dropped at a coarser level (uniform per block)
         DevTL tl;
         tl.width = c.next_width;
@@ -997,12 +1012,22 @@ __global__ __launch_bounds__(64 * LW) __attribute__((amdgpu_waves_per_eu(6, 6)))
         x = x > max_x ? max_x : x;
         y = y > max_y ? max_y : y;
         const int ox = (x / T - 8) * T, oy = (y / T - 8) * T;
+        uint32_t best = 0;
+        if constexpr (COMPACT == 3) {
+            // bit strips (sbm_local_bits.h): one wave per candidate (LW == 1), the maximum comes back in key form
+            const uint32_t* lb = (const uint32_t*)(lm + frame * lm_fs);
+            const uint32_t* fx = fxy + tl.feat_off;
+            const uint8_t* fl = flabel + tl.feat_off;
+            // counter planes per slot (a slot counts ceil(nf / 4) features)
+            if (tl.nf <= 252) best = local_best_bits<6>(lb, fx, fl, tl.nf, rows, cols, ox, oy, W, H);
+            else if (tl.nf <= 2044) best = local_best_bits<9>(lb, fx, fl, tl.nf, rows, cols, ox, oy, W, H);
+            else best = local_best_bits<12>(lb, fx, fl, tl.nf, rows, cols, ox, oy, W, H);
+        } else {
         uint32_t lo, hi;
         local_patch<COMPACT, LW, T8>(lm + frame * lm_fs, lm_stride, tl, fxy, foff, rows, cols, W, H, T, ox, oy, s_part, lo, hi, flabel,
                                  COMPACT == 2 ? fcls + ((size_t)c.t * L + l) * 17 : nullptr);
         if (wave != 0) continue;
         // first maximum in row-major order, strict '>' from 0 (:1265-1282): maximise (raw, -position)
-        uint32_t best = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             uint32_t raw = (uint32_t)unpack4(lo, hi, k);
@@ -1015,8 +1040,9 @@ __global__ __launch_bounds__(64 * LW) __attribute__((amdgpu_waves_per_eu(6, 6)))
             uint32_t o = __shfl_xor(best, s, 64);
             best = o > best ? o : best;
         }
+        }
         if (lane == 0) {
-            if (frame == 0) stat_bytes += (unsigned long long)tl.nf * 256ull; // refinement bytes (sbm_get_stats: frame 0)
+            if (frame == 0) stat_bytes += (unsigned long long)tl.nf * (COMPACT == 3 ? 128ull : 256ull); // refinement bytes (sbm_get_stats: frame 0)
             const int raw = (int)(best >> 8);
             int br = -1, bc = -1;
             if (raw > 0) {
@@ -1074,6 +1100,22 @@ __global__ __launch_bounds__(64 * LW) __attribute__((amdgpu_waves_per_eu(6, 6)))
                        mirror_count ? mirror_count + frame_wg * 2 : nullptr, slot);
     }
 }
+
+template <int COMPACT, int LW, int ORDER, bool T8 = false>
+__global__ __launch_bounds__(64 * LW) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_similarity_local(SBM_LOCAL_PARAMS)
+{
+    similarity_local_body<COMPACT, LW, ORDER, T8>(SBM_LOCAL_ARGS);
+}
+
+// the bit-strip form (sbm_local_bits.h): one wave per candidate, a window of 64 features = 32 loads per lane in flight --
+// the register budget is the compiler's (launch bound 64 threads), not the byte form's six waves per SIMD
+template <int ORDER>
+__global__ __launch_bounds__(64) void k_similarity_local_bits(SBM_LOCAL_PARAMS)
+{
+    similarity_local_body<3, 1, ORDER, false>(SBM_LOCAL_ARGS);
+}
+#undef SBM_LOCAL_PARAMS
+#undef SBM_LOCAL_ARGS
 
 // stage entry point: one 16x16 patch
 __global__ __launch_bounds__(64 * LOCAL_WAVES) void k_similarity_local_patch(const uint8_t* __restrict__ lm, int64_t lm_stride,

@@ -36,7 +36,52 @@ static uint32_t count32(const uint32_t* x, int n, int bias, int32_t* counts)
     return dead;
 }
 
+// The refinement pass on bit strips (sbm_local_bits.h) for ONE patch row: x[n] = per-feature dwords (any bits of the 16 columns
+// | exact bits << 16).  As the kernel does it: feature j goes to slot j % 4; every slot counts its features in batches of
+// 16 (a full window of 64 features) / 8 / 4 / 2; the four slot counters are added plane-wise in two steps; the row's best raw
+// (3 #any + #exact) and its first column come from bitslice_row_best.
+template <int P>
+static uint32_t row_best(const uint32_t* x, int n, int* first)
+{
+    constexpr int PM = P + 4;
+    uint32_t c[4][PM] = {};
+    for (int g = 0; g < 4; ++g) {
+        uint32_t v[8];
+        uint32_t (&cp)[P] = *(uint32_t (*)[P])&c[g][0];
+        // the slot's features in kernel order: windows of 64 features = 16 per slot
+        for (int jb = 0; jb < n; jb += 64) {
+            const int nbf = n - jb < 64 ? n - jb : 64;
+            auto fetch = [&](int u, int k) { const int j = jb + u + 4 * k + g; return u + 4 * k + g < nbf && j < n ? x[j] : 0u; };
+            int u = 0;
+            auto run = [&](int steps) {
+                for (int k = 0; k < steps; ++k) v[k] = fetch(u, k);
+                if (steps == 8) { const uint32_t b8[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}; sbm::bitslice_add8<P>(cp, b8); }
+                else if (steps == 4) sbm::bitslice_add4<P>(cp, v[0], v[1], v[2], v[3]);
+                else sbm::bitslice_add2<P>(cp, v[0], v[1]);
+            };
+            if (nbf > 32) { run(8); u = 32; run(8); }
+            else if (nbf > 16) run(8);
+            else if (nbf > 8) run(4);
+            else run(2);
+        }
+    }
+    sbm::bitslice_add_planes<P>(c[0], c[1]);
+    sbm::bitslice_add_planes<P>(c[2], c[3]);
+    sbm::bitslice_add_planes<P + 1>(c[0], c[2]);
+    return sbm::bitslice_row_best<P + 2>(c[0], first);
+}
+
 extern "C" {
+uint32_t sbm_emu_local_row_best(const uint32_t* x, int n, int P, int* first)
+{
+    switch (P) {
+    case 6: return row_best<6>(x, n, first);
+    case 9: return row_best<9>(x, n, first);
+    case 12: return row_best<12>(x, n, first);
+    default: return 0;
+    }
+}
+
 // the 32-slice form (one ripple per 32 slices); n % 32 == 0
 uint32_t sbm_emu_bitslice_count32(const uint32_t* x, int n, int P, int bias, int32_t* counts, int inv)
 {

@@ -25,6 +25,8 @@ def emu():
     L.sbm_emu_bitslice_count.restype = C.c_uint32
     L.sbm_emu_bitslice_count32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.sbm_emu_bitslice_count32.restype = C.c_uint32
+    L.sbm_emu_local_row_best.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.sbm_emu_local_row_best.restype = C.c_uint32
     return L
 
 
@@ -67,3 +69,25 @@ def test_bitsliced_counters_and_sticky_overflow(emu, P):
             ci = np.zeros(32, np.int32)
             di = emu.sbm_emu_bitslice_count(xi.ctypes.data, n, P, bias, ci.ctypes.data, 1)
             assert np.array_equal(ci, counts) and di == want_dead, (n, density, bias)
+
+
+@pytest.mark.parametrize("P,nfs", [(6, [1, 2, 3, 7, 8, 9, 17, 33, 63, 64, 65, 71, 100, 131, 252]), (9, [253, 257, 600, 1021, 2044]),
+                                   (12, [2045, 4095, 8191])])
+def test_refinement_row_on_bit_strips(emu, P, nfs):
+    """one patch row of the refinement pass on bit strips (sbm_local_bits.h): per feature 16 "response > 0" bits and 16
+    "response == 4" bits; the reference's sum of response bytes {0, 3, 4} (similarityLocal, line2Dup.cpp:860-922) is
+    3 #any + #exact, its first maximum the lowest column with the largest sum"""
+    rs = np.random.RandomState(P)
+    for nf in nfs:
+        for d_any, d_ex in ((0.5, 0.5), (0.95, 0.9), (0.05, 0.5), (1.0, 1.0), (0.0, 0.0)):
+            any_b = rs.rand(nf, 16) < d_any
+            ex_b = any_b & (rs.rand(nf, 16) < d_ex)  # an exact hit is also a hit
+            x = np.zeros(nf, np.uint32)
+            for col in range(16):
+                x |= any_b[:, col].astype(np.uint32) << np.uint32(col)
+                x |= ex_b[:, col].astype(np.uint32) << np.uint32(16 + col)
+            raw = 3 * any_b.sum(axis=0) + ex_b.sum(axis=0)
+            first = C.c_int(-1)
+            got = emu.sbm_emu_local_row_best(x.ctypes.data, nf, P, C.byref(first))
+            assert got == raw.max(), (nf, d_any)
+            assert first.value == int(np.argmax(raw)), (nf, d_any)

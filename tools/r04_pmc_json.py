@@ -15,7 +15,7 @@ import os
 import sys
 
 ALIAS = {"k_build_lm_rows": "k_build_lm", "k_quantize_stream": "k_quantize", "k_similarity_coarse_bits": "k_similarity_coarse",
-         "k_similarity_coarse_wave": "k_similarity_coarse", "k_pack_bitplanes": "k_pack_bitplanes", "k_similarity_local": "k_similarity_local"}
+         "k_similarity_coarse_wave": "k_similarity_coarse", "k_pack_bitplanes": "k_pack_bitplanes", "k_similarity_local": "k_similarity_local", "k_similarity_local_bits": "k_similarity_local"}
 WIDE_READS = {"k_build_lm_rows"}  # 16 B per lane streaming reads: FETCH_SIZE counts half of them on gfx950
 
 
