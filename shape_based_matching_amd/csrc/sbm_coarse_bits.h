@@ -64,6 +64,32 @@ __global__ __launch_bounds__(256) void k_pack_bitplanes(const uint8_t* __restric
     dst[(int64_t)(8 + o) * plane_dwords + d] = exact;
 }
 
+// spread bytes -> bit planes, flat (round 4): the producer of the match entry points on grids where the fused form of
+// k_build_lm_rows does not apply (W * H % 256 != 0, e.g. 1920 x 1072 frames: 120 x 67 cells at the coarsest level).  The
+// linear-memory launch then writes the coarsest level as ONE plane of spread bytes (1 byte per pixel instead of the 8
+// response planes) and this kernel turns 32 of them per thread into the 16 planes' dwords with the fused producer's
+// register transpose (bytes32_to_bitplanes): 1 byte per pixel read, 2 written, where k_pack_bitplanes reads 8.
+__global__ __launch_bounds__(256) void k_pack_bitplanes_spread(const uint8_t* __restrict__ spread, int64_t spread_fs, int64_t lm_stride,
+                                                               uint32_t* __restrict__ blm, int64_t blm_fs_dwords, int n_dwords)
+{
+    raise_wave_priority();
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= n_dwords) return;
+    const size_t frame = blockIdx.y;
+    const uint4* src = (const uint4*)(spread + frame * spread_fs + (size_t)d * 32);
+    const uint4 a = src[0], b = src[1];
+    uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    bytes32_to_bitplanes(w);
+    const int64_t plane_dwords = lm_stride >> 5;
+    uint32_t* dst = blm + frame * blm_fs_dwords + d;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const uint32_t e = w[bitplane_reg(o)];
+        dst[(int64_t)o * plane_dwords] = w[bitplane_reg((o + 7) & 7)] | e | w[bitplane_reg((o + 1) & 7)];
+        dst[(int64_t)(8 + o) * plane_dwords] = e;
+    }
+}
+
 // One pass over the template's nf features on one bit-plane set.  ub: the plane set of this frame (wave-uniform);
 // li: this lane's first dword of the item (item base / 32 + DW * lane), or 0 for a lane whose loads do not matter (it
 // then reads the features' own first dwords: one more cache line per load, no branch).  MISSES: count zero bits and

@@ -380,7 +380,12 @@ __device__ __forceinline__ void build_lm_strip4_allty(const uint8_t* __restrict_
                     const uint32_t any = d[bitplane_reg((o + 7) & 7)] | e | d[bitplane_reg((o + 1) & 7)];
                     const uint32_t w0 = perm_b32(e, any, 0x05040100u), w1 = perm_b32(e, any, 0x07060302u);
                     uint32_t* dst = lb + lm_bits_offset(sub * 8 + o, S, gy2, W, H);
-                    if (gy2 + 1 < H) *(u32x2_a4*)dst = u32x2_a4{w0, w1};
+                    // non-temporal: the strips are read once, by a later launch, and 2 MB per frame of them would push the
+                    // orientation maps and the coarse bit planes out of the L2s (16-frame launch 18.5 -> 16.5 us, pipelined
+                    // step 94.5 -> 92.9; the refinement launch pays 1 - 2 us for reading them from HBM)
+                    typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+                    if (gy2 + 1 < H && (H & 1) == 0) __builtin_nontemporal_store(u32x2v{w0, w1}, (u32x2v*)dst); // 8-byte aligned
+                    else if (gy2 + 1 < H) *(u32x2_a4*)dst = u32x2_a4{w0, w1};
                     else *dst = w0;
                 }
             }
