@@ -129,6 +129,24 @@ def test_feature_counts(oracle, ctx_form, nf, box):
         assert got_m == want, (bits, nf, len(got_m), len(want))
 
 
+@pytest.mark.parametrize("T", [(4, 8, 8), (4, 4, 8), (8, 4, 8)])
+def test_three_levels_mixed_forms(oracle, ctx_form, T):
+    """three-level pyramids: a T = 4 level is refined on bit strips, a T = 8 level on spread bytes, in either order --
+    the candidate records pass from one form of the pass to the other"""
+    img = synth.scene_bgr(33, 1024, 1024, n_shapes=300)
+    pyr = oracle.Pyramid.build(img, list(T), 30.0)
+    ts, got = templates_from_maps([pyr.quantized(l) for l in range(3)], [160, 80, 40], 256, 8, 5)
+    assert got == [160, 80, 40]
+    want = multiset(pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 50.0, n_threads=NT))
+    pyr.free()
+    assert len(want) >= 8
+    for bits in (True, False):
+        ctx = ctx_form(bits, T=T, max_candidates=1 << 20)
+        ctx.upload_templates(ts)
+        got_m = multiset(ctx.match(img, 50.0))
+        assert got_m == want, (bits, T, len(got_m), len(want))
+
+
 def test_batch_both_orders(oracle, ctx_form, case1):
     """6 frames through the slot order and the frame-major list order of the refinement pass, both forms"""
     import torch
