@@ -199,3 +199,44 @@ def test_stage_entry_after_a_bit_strip_build(oracle, ctx_form, case1):
         assert np.array_equal(lm[:, :n], pyr.lm(l)[:, :n]), l
     pyr.free()
     assert multiset(ctx.match_templates(80.0)) == multiset(got)
+
+
+def test_captured_template_loop_follows_the_form_of_the_levels(oracle, ctx_form, case1):
+    """graph replay of the template loop (sbm_match_templates_device with several calls in flight): a capture made on a pyramid
+    that a match call built (bit strips + bit planes) must not be replayed after a stage entry point has rebuilt the levels
+    as response planes at the same geometry -- the form of the levels is part of the graph's key"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    ts = case1["templates"].subset(range(0, 360, 6))
+    img_a = synth.embed(case1["test"], 512, 640, 10, 20)
+    img_b = synth.embed(case1["test"], 512, 640, 30, 0)
+    ctx = ctx_form(True)
+    ctx.set_pipeline_depth(2)
+    ctx.set_graph_mode(True)
+    ctx.upload_templates(ts)
+    cap, rec = 8192, MATCH_DTYPE.itemsize
+    d_out = torch.zeros(cap * rec, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+
+    def loop():
+        ctx.match_templates_device(70.0, d_out.data_ptr(), cap, d_cnt.data_ptr(), stream=stream.cuda_stream)
+        stream.synchronize()
+        n = int(d_cnt.cpu().numpy()[0])
+        return multiset(d_out.cpu().numpy().view(MATCH_DTYPE)[:n])
+
+    want_a = multiset(ctx.match(img_a, 70.0))  # builds bit strips / bit planes
+    assert len(want_a) > 0
+    assert loop() == want_a and loop() == want_a  # captured, then replayed
+    n_graphs = ctx.graph_count()
+    pyr = oracle.Pyramid.build(img_b, [4, 8], 30.0)
+    want_b = multiset(pyr.match(ts.levels, ts.features, ts.class_idx, ts.template_id, 70.0, n_threads=NT))
+    for l in range(2):
+        ctx.set_quantized(l, pyr.quantized(l))  # a stage entry point: response planes, same geometry
+    pyr.free()
+    assert want_b != want_a
+    assert loop() == want_b
+    assert ctx.graph_count() == n_graphs + 1  # a capture of its own
+    assert loop() == want_b
