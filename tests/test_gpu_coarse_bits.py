@@ -1,9 +1,10 @@
 """-m gpu: the coarsest level's BIT planes (round 4) -- what the coarse pass reads instead of the reference's one byte per
 (position, orientation) (similarity, line2Dup.cpp:843-856; SIMILARITY_LUT's values {0, 3, 4}, :632-635).
 
-Two producers must give the same planes, both equal to the oracle's byte linear memories packed by numpy
+Three producers must give the same planes, both equal to the oracle's byte linear memories packed by numpy
 (plane o: LM[o] > 0, plane 8 + o: LM[o] == 4, flat order, zero tail): the fused one inside the one-launch builder of the
-match entry points (k_build_lm_rows, compact == 3) and the generic byte -> bit pack the stage entry points use.  The
+match entry points (k_build_lm_rows, compact == 3), the spread-plane pack of the grids that one does not take
+(k_pack_bitplanes_spread) and the generic byte -> bit pack the stage entry points use.  The
 match lists through either must equal the oracle's -- also after the form of the coarsest level changed under a
 context (bits only -> response planes on demand -> bits again)."""
 import os
@@ -29,9 +30,10 @@ def packed(lm):
 @pytest.mark.parametrize("shape,T,ch", [((512, 1024), (4, 8), 3), ((1024, 1024), (4, 8), 1), ((512, 1024), (8, 8), 3), ((512, 1024), (4,), 1),
                                         ((512, 640), (4, 8), 3)])
 def test_fused_bit_planes_equal_packed_oracle_planes(oracle, ctx_factory, case1, shape, T, ch):
-    """sbm_match builds the coarsest level as bit planes only (W * H % 256 == 0) or packs them from the response planes
-    ((512, 640): W * H = 1280 is not a multiple of 256); either way they are the oracle's planes, and the response planes the
-    stage accessor then asks for are rebuilt from the orientation map"""
+    """sbm_match builds the coarsest level as bit planes only (W * H % 256 == 0) or as one plane of spread bytes that
+    k_pack_bitplanes_spread turns into them ((512, 640): W * H = 1280 is not a multiple of 256); either way they are the
+    oracle's planes, and the response planes the stage accessor then asks for are rebuilt from the orientation map /
+    expanded from the spread plane"""
     rows, cols = shape
     ts = case1["templates"].subset(range(0, 360, 9))
     if len(T) == 1:  # a one-level pyramid: the templates' level 0 alone (the coarse pass then emits the matches itself)
