@@ -189,7 +189,8 @@ int sbm_set_quantize_mode(sbm_ctx* ctx, int32_t mode, int32_t rows_per_wave);
  * 1: always the four-wave kernel; 2: always the one-wave kernel.  Identical candidates either way; a test / tuning knob. */
 int sbm_set_coarse_mode(sbm_ctx* ctx, int32_t mode);
 
-/* Which form of a refinement level with T = 4 the match entry points build and the refinement pass (similarityLocal(_64),
+/* Which form of a refinement level with T = 4 the match entry points build (and the template loop builds, once per pyramid,
+ * beside response planes that the stage entry points made) and the refinement pass (similarityLocal(_64),
  * line2Dup.cpp:860-922, :986-1048) reads.  1: BIT STRIPS -- per (sub-plane, orientation, strip of 16 columns, grid row) one
  * dword, "response > 0" bits of the 16 cells | "response == 4" bits << 16; the reference's sum of response bytes {0, 3, 4}
  * is 3 #any + #exact, counted with bit-sliced carry-save counters, one wave per candidate.  0: one plane of spread bytes,
