@@ -383,10 +383,11 @@ int sbm_get_timings(sbm_ctx* ctx, const char** names, float* ms, int32_t cap, in
 int sbm_coarse_bytes(sbm_ctx* ctx, int64_t* bytes);
 
 /* Counters of the last template-matching call: coarse candidates found
- * (line2Dup.cpp:1208-1214) and the algorithmic bytes of the refinement passes,
- * sum over refined candidates of nf_level * 256 (accumulated only
- * while profiling is enabled, to keep the atomic out of the throughput path).
- * Synchronises. */
+ * (line2Dup.cpp:1208-1214) and the bytes the refinement passes read for frame 0,
+ * sum over refined candidates of nf_level * 256 on response / spread bytes (the
+ * reference's figure) and nf_level * 128 on bit strips
+ * (sbm_set_refine_bits); accumulated only while profiling is enabled, to keep the
+ * atomic out of the throughput path.  Synchronises. */
 int sbm_get_stats(sbm_ctx* ctx, int64_t* n_candidates, int64_t* refine_bytes);
 
 #ifdef __cplusplus
