@@ -801,7 +801,8 @@ def main():
         limiter = {
             "k_quantize": "vector-instruction issue (integer VALU at one wave-instruction per 4 cycles per SIMD); HBM traffic "
                           "equals the algorithmic bytes",
-            "k_build_lm": "memory latency of a short load - compute - store item (HBM traffic 45 MB per 16-frame launch)",
+            "k_build_lm": "its stores: 2 bytes per pixel of bit strips / bit planes in 128-byte runs (20 MB in, 41 MB out per 16-frame "
+                          "launch; the same launch without its level-0 stores takes 11.5 of the 16.4 us)",
             "k_similarity_coarse": "bit-plane kernel: vector issue of the bit-sliced counters and L2 -> L1 bandwidth of the items still "
                                    "alive on large template sets (c4: both near their ceilings); the longest work items' chain of "
                                    "dependent L2 round trips on a 16-frame case1 launch",
